@@ -1,0 +1,185 @@
+"""Architecture tables: `state_dict` key names and shapes of the reference modules on the hot path.
+
+Pure Python (no torch): used by the nn.Module shims to create parameters under the reference's key
+names, by the tests to build closed-form weights, and mirrored by the C++ plan builder
+(csrc/plan.cpp), which consumes tensors in exactly the order these generators yield them.
+"""
+
+POLY_ENC = [(64, 64, 64, 2), (64, 128, 128, 2), (128, 256, 256, 2)]
+POLY_DEC = [(256, 128, 128, 2), (128, 128, 64, 2), (64, 64, 64, 2)]
+CEL_IMG_ENC = [(64, 128, 128, 2), (128, 256, 256, 2), (256, 512, 512, 2)]
+CEL_IMG_DEC = [(512, 512, 256, 2), (256, 256, 128, 2), (128, 128, 64, 2)]
+CEL_MASK_ENC = [(64, 128, 128, 4), (128, 256, 256, 4)]
+CEL_MASK_DEC = [(256, 256, 128, 4), (128, 128, 64, 4)]
+
+ATTN_HEADS, ATTN_DIM_HEAD = 4, 32          # unet_model.py:127,152 defaults, never overridden
+
+
+def unet_dims(dim, channels, dim_mults, init_dim=None, out_dim=None):
+    """(init_dim, dims, in_out, out_dim) as unet_model.py:206-212,269 derive them."""
+    init_dim = init_dim if init_dim is not None else dim // 3 * 2
+    dims = [init_dim] + [dim * m for m in dim_mults]
+    return init_dim, dims, list(zip(dims[:-1], dims[1:])), (out_dim if out_dim is not None else channels)
+
+
+def _convnext(pre, cin, cout, time_dim, mult=2):
+    """ConvNextBlock parameters (unet_model.py:95-113)."""
+    if time_dim:
+        yield pre + "mlp.1.weight", (cin, time_dim)
+        yield pre + "mlp.1.bias", (cin,)
+    yield pre + "ds_conv.weight", (cin, 1, 7, 7)
+    yield pre + "ds_conv.bias", (cin,)
+    yield pre + "net.0.weight", (cin,)
+    yield pre + "net.0.bias", (cin,)
+    yield pre + "net.1.weight", (cout * mult, cin, 3, 3)
+    yield pre + "net.1.bias", (cout * mult,)
+    yield pre + "net.3.weight", (cout * mult,)
+    yield pre + "net.3.bias", (cout * mult,)
+    yield pre + "net.4.weight", (cout, cout * mult, 3, 3)
+    yield pre + "net.4.bias", (cout,)
+    if cin != cout:
+        yield pre + "res_conv.weight", (cout, cin, 1, 1)
+        yield pre + "res_conv.bias", (cout,)
+
+
+def _attn(pre, c, linear):
+    """Residual(PreNorm(c, [Linear]Attention(c))) parameters (unet_model.py:126-187)."""
+    hid = ATTN_HEADS * ATTN_DIM_HEAD
+    yield pre + "fn.fn.to_qkv.weight", (hid * 3, c, 1, 1)
+    if linear:
+        yield pre + "fn.fn.to_out.0.weight", (c, hid, 1, 1)
+        yield pre + "fn.fn.to_out.0.bias", (c,)
+        yield pre + "fn.fn.to_out.1.weight", (c,)
+        yield pre + "fn.fn.to_out.1.bias", (c,)
+    else:
+        yield pre + "fn.fn.to_out.weight", (c, hid, 1, 1)
+        yield pre + "fn.fn.to_out.bias", (c,)
+    yield pre + "fn.norm.weight", (c,)
+    yield pre + "fn.norm.bias", (c,)
+
+
+def unet_entries(dim, channels=3, dim_mults=(1, 2, 4, 8), init_dim=None, out_dim=None, with_time_emb=True,
+                 convnext_mult=2):
+    """(name, shape) in registration order of reference Unet.__init__ (unet_model.py:189-273)."""
+    init_dim, dims, in_out, out_dim = unet_dims(dim, channels, dim_mults, init_dim, out_dim)
+    td = dim * 4 if with_time_emb else 0
+    yield "init_conv.weight", (init_dim, channels, 7, 7)
+    yield "init_conv.bias", (init_dim,)
+    if td:
+        yield "time_mlp.1.weight", (td, dim)
+        yield "time_mlp.1.bias", (td,)
+        yield "time_mlp.3.weight", (td, td)
+        yield "time_mlp.3.bias", (td,)
+    n = len(in_out)
+    for i, (ci, co) in enumerate(in_out):
+        yield from _convnext(f"downs.{i}.0.", ci, co, td, convnext_mult)
+        yield from _convnext(f"downs.{i}.1.", co, co, td, convnext_mult)
+        yield from _attn(f"downs.{i}.2.", co, True)
+        if i < n - 1:
+            yield f"downs.{i}.3.weight", (co, co, 4, 4)
+            yield f"downs.{i}.3.bias", (co,)
+    mid = dims[-1]
+    yield from _convnext("mid_block1.", mid, mid, td, convnext_mult)
+    yield from _attn("mid_attn.", mid, False)
+    yield from _convnext("mid_block2.", mid, mid, td, convnext_mult)
+    for i, (ci, co) in enumerate(reversed(in_out[1:])):
+        yield from _convnext(f"ups.{i}.0.", co * 2, ci, td, convnext_mult)
+        yield from _convnext(f"ups.{i}.1.", ci, ci, td, convnext_mult)
+        yield from _attn(f"ups.{i}.2.", ci, True)
+        yield f"ups.{i}.3.weight", (ci, ci, 4, 4)          # ConvTranspose2d: (in, out, kh, kw)
+        yield f"ups.{i}.3.bias", (ci,)
+    yield from _convnext("final_conv.0.", dim, dim, 0, convnext_mult)
+    yield "final_conv.1.weight", (out_dim, dim, 1, 1)
+    yield "final_conv.1.bias", (out_dim,)
+
+
+def unet_state_shapes(**kw):
+    return dict(unet_entries(**kw))
+
+
+def _bn(pre, c):
+    yield pre + "weight", (c,)
+    yield pre + "bias", (c,)
+    yield pre + "running_mean", (c,)
+    yield pre + "running_var", (c,)
+    yield pre + "num_batches_tracked", ()
+
+
+def _rblock(pre, cin, cmid, cout):
+    """RBlock / RBlockN parameters (h_vae_model_copy.py:17-26, 355-364); size_conv always exists."""
+    yield pre + "conv.0.weight", (cmid, cin, 3, 3)
+    yield from _bn(pre + "conv.1.", cmid)
+    yield pre + "conv.3.weight", (cout, cmid, 3, 3)
+    yield from _bn(pre + "conv.4.", cout)
+    yield pre + "size_conv.weight", (cout, cin, 1, 1)
+
+
+def resvae_geometry(enc_channel_list, size_in):
+    """(init_size, c_last, size_z_lin) as ResVAE.__init__ derives them (h_vae_model_copy.py:105-113)."""
+    init_size = size_in
+    for c in enc_channel_list:
+        init_size //= c[3]
+    c_last = enc_channel_list[-1][2]
+    return init_size, c_last, init_size * init_size * c_last
+
+
+def resvae_entries(variant, enc_channel_list, dec_channel_list, size_in=64, size_z=64, img_ch=3):
+    """ResVAE / ResAE / ResVAEN / ResAEN state_dict (h_vae_model_copy.py:91-174, 457-588)."""
+    enc_half = (size_in // 2)
+    for c in enc_channel_list:
+        enc_half //= c[3]
+    enc_lin = enc_half * enc_half * (enc_channel_list[-1][2] // 2)
+    c0 = enc_channel_list[0][0]
+    yield "enc.ch_enc.0.weight", (c0, img_ch, 5, 5)
+    yield "enc.ch_enc.0.bias", (c0,)
+    yield from _bn("enc.ch_enc.1.", c0)
+    for i, (ci, cm, co, _r) in enumerate(enc_channel_list):
+        yield from _rblock(f"enc.r_blocks.{i}.", ci, cm, co)
+    yield "enc.mu_lin.weight", (size_z, enc_lin)
+    yield "enc.mu_lin.bias", (size_z,)
+    yield "enc.logvar_lin.weight", (size_z, enc_lin)
+    yield "enc.logvar_lin.bias", (size_z,)
+    for i, (ci, cm, co, _r) in enumerate(dec_channel_list):
+        yield from _rblock(f"dec.r_blocks.{i}.", ci, cm, co)
+    c = dec_channel_list[-1][2]
+    yield from _rblock("dec.ch_dec.0.", c, c, c)
+    yield "dec.ch_dec.1.weight", (img_ch, c, 5, 5)
+    yield "dec.ch_dec.1.bias", (img_ch,)
+    _, _, zl = resvae_geometry(enc_channel_list, size_in)
+    yield "z_lin.weight", (zl, size_z)
+    yield "z_lin.bias", (zl,)
+
+
+def resvae_state_shapes(variant, enc_channel_list, dec_channel_list, size_in=64, size_z=64, img_ch=3):
+    return dict(resvae_entries(variant, enc_channel_list, dec_channel_list, size_in, size_z, img_ch))
+
+
+ATTR_DEC_WIDTHS = (512, 512, 512, 256, 128)
+ATTR_ENC_WIDTHS = (128, 256, 512, 512, 512)
+
+
+def attr_entries(size_z=64, att_size=18, ae=False):
+    """CelebAAttrNewBN / CelebAAttrNewBNAE state_dict (h_vae_model.py:712-757, 839-882)."""
+    prev = att_size
+    for i, w in enumerate(ATTR_ENC_WIDTHS):
+        yield f"enc_net.{3 * i}.weight", (w, prev)
+        yield f"enc_net.{3 * i}.bias", (w,)
+        yield from _bn(f"enc_net.{3 * i + 1}.", w)
+        prev = w
+    yield "mu_lin.weight", (size_z, prev)
+    yield "mu_lin.bias", (size_z,)
+    if not ae:
+        yield "logvar_lin.weight", (size_z, prev)
+        yield "logvar_lin.bias", (size_z,)
+    prev = size_z
+    for i, w in enumerate(ATTR_DEC_WIDTHS):
+        yield f"dec_net.{3 * i}.weight", (w, prev)
+        yield f"dec_net.{3 * i}.bias", (w,)
+        yield from _bn(f"dec_net.{3 * i + 1}.", w)
+        prev = w
+    yield "dec_net.15.weight", (att_size, prev)
+    yield "dec_net.15.bias", (att_size,)
+
+
+def attr_state_shapes(size_z=64, att_size=18, ae=False):
+    return dict(attr_entries(size_z, att_size, ae))
