@@ -1,0 +1,307 @@
+// interp.cpp -- TEST-ONLY scalar host interpreter of a Plan.
+//
+// Built with g++ into libsbmae_planref.so (never linked into the product library).  It executes the
+// op descriptors of plan.h with plain loops on host memory, in the same PBC layout and with the same
+// partial-statistics plumbing as the HIP kernels, so that the plan builder / weight packer can be
+// checked against the oracle on a machine without a GPU, and so that each HIP kernel can be tested
+// against the descriptor semantics op by op.  It is not a fallback: nothing in the product path
+// references it.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "plan.h"
+
+namespace sbm {
+
+static inline float act_apply(int act, float v) {
+  switch (act) {
+    case ACT_GELU: return 0.5f * v * (1.0f + (float)std::erf((double)v * 0.70710678118654752440));
+    case ACT_LRELU02: return v >= 0.f ? v : 0.2f * v;
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_SIGMOID: return (float)(1.0 / (1.0 + std::exp(-(double)v)));
+    case ACT_SILU: return (float)((double)v / (1.0 + std::exp(-(double)v)));
+    default: return v;
+  }
+}
+
+static void gn_mean_rstd(const float* ws, int64_t part_off, int nparts, int B, int b, float inv_count, float* mean, float* rstd) {
+  double s = 0, q = 0;
+  for (int i = 0; i < nparts; ++i) {
+    s += ws[part_off + ((int64_t)i * B + b) * 2 + 0];
+    q += ws[part_off + ((int64_t)i * B + b) * 2 + 1];
+  }
+  double m = s * inv_count;
+  double var = q * inv_count - m * m;
+  if (var < 0) var = 0;
+  *mean = (float)m;
+  *rstd = (float)(1.0 / std::sqrt(var + 1e-5));
+}
+
+static void run_gemm(const GemmOp& g, const float* prm, float* ws, const float* ext_in, float* ext_out) {
+  const int B = g.B, P = g.Hout * g.Wout;
+  const int nstore = g.out_nchw ? g.N : g.out.C;
+  const int ntiles = ceil_div(nstore, g.BN);
+  const float* Abase = g.a_ext ? ext_in : ws;
+  std::vector<float> mean(B, 0.f), rstd(B, 1.f);
+  if (g.gn) for (int b = 0; b < B; ++b) gn_mean_rstd(ws, g.gn_part_off, g.gn_nparts, B, b, g.gn_inv_count, &mean[b], &rstd[b]);
+  std::vector<float> arow((size_t)g.KH * g.KW * g.a.C + (g.has2 ? g.a2.C : 0));
+  std::vector<int> taps; std::vector<int> srcs;
+  for (int p = 0; p < P; ++p) {
+    const int oy = p / g.Wout, ox = p % g.Wout;
+    taps.clear(); srcs.clear();
+    for (int ky = 0; ky < g.KH; ++ky) for (int kx = 0; kx < g.KW; ++kx) {
+      int q = g.a_bcast ? 0 : tap_source_pixel(oy, ox, ky, kx, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W);
+      if (q >= 0) { taps.push_back(ky * g.KW + kx); srcs.push_back(q); }
+    }
+    const int p2 = (oy / g.up2) * (g.has2 ? g.a2.W : (g.has_res ? g.r.W : 1)) + (ox / g.up2);
+    const float* W = prm + g.w_off + (int64_t)p * g.w_pix_stride;
+    const float* bias = g.bias_off >= 0 ? prm + g.bias_off + (int64_t)p * g.bias_pix_stride : nullptr;
+    for (int b = 0; b < B; ++b) {
+      // gather the (GroupNorm-transformed) A row for this output pixel
+      for (size_t t = 0; t < taps.size(); ++t) {
+        const float* a = Abase + g.a.off + ((int64_t)srcs[t] * B + b) * g.a.ld;
+        float* dst = &arow[t * g.a.C];
+        if (g.gn) {
+          const float* ga = prm + g.gn_gamma_off; const float* be = prm + g.gn_beta_off;
+          for (int k = 0; k < g.a.C; ++k) dst[k] = ((a[k] - mean[b]) * rstd[b]) * ga[k] + be[k];
+        } else {
+          std::memcpy(dst, a, sizeof(float) * g.a.C);
+        }
+      }
+      const float* a2 = g.has2 ? ws + g.a2.off + ((int64_t)p2 * B + b) * g.a2.ld : nullptr;
+      std::vector<double> tsum(ntiles, 0.0), tsq(ntiles, 0.0);
+      for (int n = 0; n < nstore; ++n) {
+        float acc = 0.f;
+        for (size_t t = 0; t < taps.size(); ++t) {
+          const float* w = W + ((int64_t)taps[t] * g.Npad + n) * g.a.C;
+          const float* a = &arow[t * g.a.C];
+          for (int k = 0; k < g.a.C; ++k) acc = std::fmaf(a[k], w[k], acc);
+        }
+        if (g.has2) {
+          const float* w2 = prm + g.w2_off + (int64_t)n * g.a2.C;
+          for (int k = 0; k < g.a2.C; ++k) acc = std::fmaf(a2[k], w2[k], acc);
+        }
+        float v = acc;
+        if (bias) v += bias[n];
+        if (g.has_res) v += ws[g.r.off + ((int64_t)p2 * B + b) * g.r.ld + n];
+        v = act_apply(g.act, v);
+        if (g.out_nchw) {
+          const int y = oy - g.crop_y, x = ox - g.crop_x;
+          if (y >= 0 && y < g.Hn && x >= 0 && x < g.Wn) ext_out[(((int64_t)b * g.N + n) * g.Hn + y) * g.Wn + x] = v;
+        } else {
+          ws[g.out.off + ((int64_t)p * B + b) * g.out.ld + n] = v;
+        }
+        tsum[n / g.BN] += v; tsq[n / g.BN] += (double)v * v;
+      }
+      if (g.stat_off >= 0)
+        for (int t = 0; t < ntiles; ++t) {
+          ws[g.stat_off + (((int64_t)p * ntiles + t) * B + b) * 2 + 0] = (float)tsum[t];
+          ws[g.stat_off + (((int64_t)p * ntiles + t) * B + b) * 2 + 1] = (float)tsq[t];
+        }
+    }
+  }
+}
+
+static void run_dw(const DwOp& d, const float* prm, float* ws) {
+  const int B = d.B, H = d.in.H, W = d.in.W, C = d.in.C;
+  for (int p = 0; p < H * W; ++p) {
+    const int oy = p / W, ox = p % W;
+    for (int b = 0; b < B; ++b) {
+      double s = 0, q = 0;
+      float* o = ws + d.out.off + ((int64_t)p * B + b) * d.out.ld;
+      for (int c = 0; c < C; ++c) {
+        float acc = 0.f;
+        for (int ky = 0; ky < 7; ++ky) for (int kx = 0; kx < 7; ++kx) {
+          const int iy = oy - 3 + ky, ix = ox - 3 + kx;
+          if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+          acc = std::fmaf(ws[d.in.off + ((int64_t)(iy * W + ix) * B + b) * d.in.ld + c], prm[d.w_off + (int64_t)(ky * 7 + kx) * C + c], acc);
+        }
+        acc += prm[d.bias_off + c];
+        if (d.has_cond) acc += ws[d.cond_off + (int64_t)b * d.cond_ld + c];
+        o[c] = acc; s += acc; q += (double)acc * acc;
+      }
+      if (d.stat_off >= 0) { ws[d.stat_off + ((int64_t)p * B + b) * 2] = (float)s; ws[d.stat_off + ((int64_t)p * B + b) * 2 + 1] = (float)q; }
+    }
+  }
+}
+
+static void run_attn(const AttnOp& a, bool linear, float* ws) {
+  const int B = a.B, n = a.qkv.H * a.qkv.W, hd = a.heads * a.dh, dh = a.dh;
+  std::vector<double> q((size_t)dh * n), k((size_t)dh * n), v((size_t)dh * n);
+  for (int b = 0; b < B; ++b) for (int h = 0; h < a.heads; ++h) {
+    for (int d = 0; d < dh; ++d) for (int i = 0; i < n; ++i) {
+      const float* row = ws + a.qkv.off + ((int64_t)i * B + b) * a.qkv.ld;
+      q[(size_t)d * n + i] = row[h * dh + d]; k[(size_t)d * n + i] = row[hd + h * dh + d]; v[(size_t)d * n + i] = row[2 * hd + h * dh + d];
+    }
+    if (linear) {
+      // q softmax over d, k softmax over n, q *= scale; ctx[d][e] = sum_n k[d][n] v[e][n]; out[e][n] = sum_d ctx[d][e] q[d][n]
+      for (int i = 0; i < n; ++i) {
+        double m = -1e300, s = 0; for (int d = 0; d < dh; ++d) m = std::max(m, q[(size_t)d * n + i]);
+        for (int d = 0; d < dh; ++d) { q[(size_t)d * n + i] = std::exp(q[(size_t)d * n + i] - m); s += q[(size_t)d * n + i]; }
+        for (int d = 0; d < dh; ++d) q[(size_t)d * n + i] = q[(size_t)d * n + i] / s * a.scale;
+      }
+      for (int d = 0; d < dh; ++d) {
+        double m = -1e300, s = 0; for (int i = 0; i < n; ++i) m = std::max(m, k[(size_t)d * n + i]);
+        for (int i = 0; i < n; ++i) { k[(size_t)d * n + i] = std::exp(k[(size_t)d * n + i] - m); s += k[(size_t)d * n + i]; }
+        for (int i = 0; i < n; ++i) k[(size_t)d * n + i] /= s;
+      }
+      std::vector<double> ctx((size_t)dh * dh, 0.0);
+      for (int d = 0; d < dh; ++d) for (int e = 0; e < dh; ++e) { double s = 0; for (int i = 0; i < n; ++i) s += k[(size_t)d * n + i] * v[(size_t)e * n + i]; ctx[(size_t)d * dh + e] = s; }
+      for (int e = 0; e < dh; ++e) for (int i = 0; i < n; ++i) {
+        double s = 0; for (int d = 0; d < dh; ++d) s += ctx[(size_t)d * dh + e] * q[(size_t)d * n + i];
+        ws[a.out.off + ((int64_t)i * B + b) * a.out.ld + h * dh + e] = (float)s;
+      }
+    } else {
+      // sim[i][j] = sum_d scale*q[d][i] k[d][j]; softmax_j; out[i][d] = sum_j attn[i][j] v[d][j]
+      std::vector<double> sim(n);
+      for (int i = 0; i < n; ++i) {
+        double m = -1e300, s = 0;
+        for (int j = 0; j < n; ++j) { double t = 0; for (int d = 0; d < dh; ++d) t += q[(size_t)d * n + i] * a.scale * k[(size_t)d * n + j]; sim[j] = t; m = std::max(m, t); }
+        for (int j = 0; j < n; ++j) { sim[j] = std::exp(sim[j] - m); s += sim[j]; }
+        for (int d = 0; d < dh; ++d) {
+          double t = 0; for (int j = 0; j < n; ++j) t += sim[j] / s * v[(size_t)d * n + j];
+          ws[a.out.off + ((int64_t)i * B + b) * a.out.ld + h * dh + d] = (float)t;
+        }
+      }
+    }
+  }
+}
+
+static void run_gn_res(const GnResOp& g, const float* prm, float* ws) {
+  const int B = g.B, P = g.u.H * g.u.W, C = g.u.C;
+  for (int b = 0; b < B; ++b) {
+    float mean, rstd; gn_mean_rstd(ws, g.part_off, g.nparts, B, b, g.inv_count, &mean, &rstd);
+    for (int p = 0; p < P; ++p) for (int c = 0; c < C; ++c) {
+      float u = ws[g.u.off + ((int64_t)p * B + b) * g.u.ld + c];
+      float y = ((u - mean) * rstd) * prm[g.gamma_off + c] + prm[g.beta_off + c];
+      ws[g.out.off + ((int64_t)p * B + b) * g.out.ld + c] = y + ws[g.x.off + ((int64_t)p * B + b) * g.x.ld + c];
+    }
+  }
+}
+
+static void run_bilinear(const BilinearOp& o, float* ws) {
+  const int B = o.B, Hi = o.in.H, Wi = o.in.W, Ho = o.out.H, Wo = o.out.W, C = o.in.C, s = o.scale;
+  for (int oy = 0; oy < Ho; ++oy) for (int ox = 0; ox < Wo; ++ox) {
+    float sy = std::max((oy + 0.5f) / s - 0.5f, 0.f), sx = std::max((ox + 0.5f) / s - 0.5f, 0.f);
+    int y0 = std::min((int)sy, Hi - 1), x0 = std::min((int)sx, Wi - 1);
+    int y1 = std::min(y0 + 1, Hi - 1), x1 = std::min(x0 + 1, Wi - 1);
+    float ly = sy - y0, lx = sx - x0;
+    for (int b = 0; b < B; ++b) for (int c = 0; c < C; ++c) {
+      auto at = [&](int y, int x) { return ws[o.in.off + ((int64_t)(y * Wi + x) * B + b) * o.in.ld + c]; };
+      float top = at(y0, x0) * (1.f - lx) + at(y0, x1) * lx, bot = at(y1, x0) * (1.f - lx) + at(y1, x1) * lx;
+      ws[o.out.off + ((int64_t)(oy * Wo + ox) * B + b) * o.out.ld + c] = top * (1.f - ly) + bot * ly;
+    }
+  }
+}
+
+void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const float* t, float* out) {
+  const float* prm = plan.params.data();
+  if (plan.time_off >= 0 && t) std::memcpy(&ws[plan.time_off], t, sizeof(float) * plan.B);
+  for (const Op& op : plan.ops) {
+    switch (op.kind) {
+      case OP_GEMM: run_gemm(op.g, prm, ws.data(), in, out); break;
+      case OP_DWCONV7: run_dw(op.dw, prm, ws.data()); break;
+      case OP_LINATTN: run_attn(op.at, true, ws.data()); break;
+      case OP_ATTN: run_attn(op.at, false, ws.data()); break;
+      case OP_GN_RES: run_gn_res(op.gr, prm, ws.data()); break;
+      case OP_SINUS: {
+        const SinusOp& s = op.si; const int half = s.dim / 2;
+        for (int b = 0; b < s.B; ++b) for (int j = 0; j < half; ++j) {
+          float arg = ws[plan.time_off + b] * prm[s.freq_off + j];
+          ws[s.out_off + (int64_t)b * s.ld + j] = (float)std::sin((double)arg);
+          ws[s.out_off + (int64_t)b * s.ld + half + j] = (float)std::cos((double)arg);
+        }
+        for (int b = 0; b < s.B; ++b) for (int j = 2 * half; j < s.ld; ++j) ws[s.out_off + (int64_t)b * s.ld + j] = 0.f;
+      } break;
+      case OP_NCHW_TO_PBC: {
+        const CvtOp& c = op.cv; const View& o = c.out;
+        for (int p = 0; p < o.H * o.W; ++p) for (int b = 0; b < c.B; ++b) for (int ch = 0; ch < o.C; ++ch) {
+          int y = p / o.W - c.pad_y, x = p % o.W - c.pad_x;
+          float v = 0.f;
+          if (ch < c.C && y >= 0 && y < c.Hn && x >= 0 && x < c.Wn) v = in[(((int64_t)b * c.C + ch) * c.Hn + y) * c.Wn + x];
+          ws[o.off + ((int64_t)p * c.B + b) * o.ld + ch] = v;
+        }
+      } break;
+      case OP_BILINEAR: run_bilinear(op.bl, ws.data()); break;
+      default: break;
+    }
+  }
+}
+
+}  // namespace sbm
+
+// ------------------------------------------------------------------------------------------------
+// C test API (ctypes)
+// ------------------------------------------------------------------------------------------------
+using namespace sbm;
+
+struct RefHandle { Plan plan; std::vector<float> ws; };
+static thread_local std::string g_err;
+
+static UnetCfg unet_cfg_from_ints(const int* c) {
+  // [dim, channels, init_dim, out_dim, with_time_emb, convnext_mult, H, W, n_mults, mults...]
+  UnetCfg u; u.dim = c[0]; u.channels = c[1]; u.init_dim = c[2]; u.out_dim = c[3]; u.with_time_emb = c[4]; u.convnext_mult = c[5];
+  u.H = c[6]; u.W = c[7]; u.n_mults = c[8];
+  for (int i = 0; i < u.n_mults && i < 8; ++i) u.dim_mults[i] = c[9 + i];
+  return u;
+}
+static ResDecCfg resdec_cfg_from_ints(const int* c) {
+  // [variant, size_in, size_z, img_ch, n_enc, n_dec, enc(4*n_enc)..., dec(4*n_dec)...]
+  ResDecCfg r; r.variant = c[0]; r.size_in = c[1]; r.size_z = c[2]; r.img_ch = c[3]; r.n_enc = c[4]; r.n_dec = c[5];
+  const int* e = c + 6;
+  for (int i = 0; i < r.n_enc; ++i) for (int j = 0; j < 4; ++j) r.enc[i][j] = *e++;
+  for (int i = 0; i < r.n_dec; ++i) for (int j = 0; j < 4; ++j) r.dec[i][j] = *e++;
+  return r;
+}
+
+extern "C" {
+
+const char* sbmref_error() { return g_err.c_str(); }
+
+void* sbmref_build(int kind, const int* cfg, int B, int z_ld, const float* const* tensors) {
+  RefHandle* h = new RefHandle();
+  bool ok = false;
+  if (kind == 0) ok = build_unet_plan(unet_cfg_from_ints(cfg), B, tensors, &h->plan);
+  else if (kind == 1) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);
+  else if (kind == 2) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, B, z_ld, tensors, &h->plan); }
+  if (!ok) { g_err = h->plan.error.empty() ? "unknown plan kind" : h->plan.error; delete h; return nullptr; }
+  h->ws.assign((size_t)h->plan.ws_floats, std::nanf(""));      // poison: every read must be preceded by a write
+  return h;
+}
+
+int sbmref_num_specs(int kind, const int* cfg) {
+  if (kind == 0) return (int)unet_tensor_specs(unet_cfg_from_ints(cfg)).size();
+  if (kind == 1) return (int)resdec_tensor_specs(resdec_cfg_from_ints(cfg)).size();
+  AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1];
+  return (int)attrdec_tensor_specs(a).size();
+}
+
+long sbmref_spec(int kind, const int* cfg, int i, char* name, int cap) {
+  std::vector<TensorSpec> s;
+  if (kind == 0) s = unet_tensor_specs(unet_cfg_from_ints(cfg));
+  else if (kind == 1) s = resdec_tensor_specs(resdec_cfg_from_ints(cfg));
+  else { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; s = attrdec_tensor_specs(a); }
+  if (i < 0 || i >= (int)s.size()) return -1;
+  std::strncpy(name, s[i].name.c_str(), cap - 1); name[cap - 1] = 0;
+  return (long)s[i].numel();
+}
+
+int sbmref_run(void* hv, const float* in, const float* t, float* out) {
+  RefHandle* h = (RefHandle*)hv;
+  interpret(h->plan, h->ws, in, t, out);
+  return 0;
+}
+
+// info: [n_ops, ws_floats, params_floats, flops_dense, flops_exec, n_gemm]
+void sbmref_info(void* hv, double* o) {
+  RefHandle* h = (RefHandle*)hv;
+  int ng = 0; for (auto& op : h->plan.ops) ng += op.kind == OP_GEMM;
+  o[0] = (double)h->plan.ops.size(); o[1] = (double)h->plan.ws_floats; o[2] = (double)h->plan.params.size();
+  o[3] = h->plan.flops_dense; o[4] = h->plan.flops_exec; o[5] = ng;
+}
+
+void sbmref_free(void* hv) { delete (RefHandle*)hv; }
+
+}  // extern "C"

@@ -1,0 +1,774 @@
+// plan.cpp -- host-side plan builder and weight packer (pure C++, no HIP).
+//
+// Walks the reference architectures (unet_model.Unet, h_vae_model_copy.Res*VAE*.decoder,
+// h_vae_model.CelebAAttrNewBN*.decoder) and emits a straight-line list of fused ops over the PBC
+// layout described in plan.h, packing every weight tensor into the layout its kernel reads.
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+
+namespace sbm {
+
+static int pad8(int c) { return round_up(c, 8); }
+
+// ------------------------------------------------------------------------------------------------
+// tensor specs (mirror of arch.py)
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct SpecList {
+  std::vector<TensorSpec> v;
+  void add(const std::string& n, std::vector<int64_t> s) { v.push_back({n, std::move(s)}); }
+};
+
+void spec_convnext(SpecList& L, const std::string& pre, int cin, int cout, int td, int mult) {
+  if (td) { L.add(pre + "mlp.1.weight", {cin, td}); L.add(pre + "mlp.1.bias", {cin}); }
+  L.add(pre + "ds_conv.weight", {cin, 1, 7, 7}); L.add(pre + "ds_conv.bias", {cin});
+  L.add(pre + "net.0.weight", {cin}); L.add(pre + "net.0.bias", {cin});
+  L.add(pre + "net.1.weight", {cout * mult, cin, 3, 3}); L.add(pre + "net.1.bias", {cout * mult});
+  L.add(pre + "net.3.weight", {cout * mult}); L.add(pre + "net.3.bias", {cout * mult});
+  L.add(pre + "net.4.weight", {cout, cout * mult, 3, 3}); L.add(pre + "net.4.bias", {cout});
+  if (cin != cout) { L.add(pre + "res_conv.weight", {cout, cin, 1, 1}); L.add(pre + "res_conv.bias", {cout}); }
+}
+
+void spec_attn(SpecList& L, const std::string& pre, int c, bool linear) {
+  const int hid = 128;
+  L.add(pre + "fn.fn.to_qkv.weight", {hid * 3, c, 1, 1});
+  if (linear) {
+    L.add(pre + "fn.fn.to_out.0.weight", {c, hid, 1, 1}); L.add(pre + "fn.fn.to_out.0.bias", {c});
+    L.add(pre + "fn.fn.to_out.1.weight", {c}); L.add(pre + "fn.fn.to_out.1.bias", {c});
+  } else {
+    L.add(pre + "fn.fn.to_out.weight", {c, hid, 1, 1}); L.add(pre + "fn.fn.to_out.bias", {c});
+  }
+  L.add(pre + "fn.norm.weight", {c}); L.add(pre + "fn.norm.bias", {c});
+}
+
+struct UnetDims {
+  int init_dim, out_dim, td;
+  std::vector<int> dims;
+  std::vector<std::pair<int, int>> in_out;
+};
+
+UnetDims unet_dims(const UnetCfg& c) {
+  UnetDims d;
+  d.init_dim = c.init_dim > 0 ? c.init_dim : c.dim / 3 * 2;       // unet_model.py:206
+  d.out_dim = c.out_dim > 0 ? c.out_dim : c.channels;              // unet_model.py:269
+  d.td = c.with_time_emb ? c.dim * 4 : 0;
+  d.dims.push_back(d.init_dim);
+  for (int i = 0; i < c.n_mults; ++i) d.dims.push_back(c.dim * c.dim_mults[i]);
+  for (size_t i = 0; i + 1 < d.dims.size(); ++i) d.in_out.push_back({d.dims[i], d.dims[i + 1]});
+  return d;
+}
+
+void spec_rblock(SpecList& L, const std::string& pre, int cin, int cmid, int cout) {
+  auto bn = [&](const std::string& p, int c) {
+    L.add(p + "weight", {c}); L.add(p + "bias", {c}); L.add(p + "running_mean", {c}); L.add(p + "running_var", {c});
+  };
+  L.add(pre + "conv.0.weight", {cmid, cin, 3, 3}); bn(pre + "conv.1.", cmid);
+  L.add(pre + "conv.3.weight", {cout, cmid, 3, 3}); bn(pre + "conv.4.", cout);
+  L.add(pre + "size_conv.weight", {cout, cin, 1, 1});
+}
+
+}  // namespace
+
+std::vector<TensorSpec> unet_tensor_specs(const UnetCfg& c) {
+  UnetDims d = unet_dims(c);
+  SpecList L;
+  L.add("init_conv.weight", {d.init_dim, c.channels, 7, 7}); L.add("init_conv.bias", {d.init_dim});
+  if (d.td) {
+    L.add("time_mlp.1.weight", {d.td, c.dim}); L.add("time_mlp.1.bias", {d.td});
+    L.add("time_mlp.3.weight", {d.td, d.td}); L.add("time_mlp.3.bias", {d.td});
+  }
+  const int n = (int)d.in_out.size();
+  for (int i = 0; i < n; ++i) {
+    auto [ci, co] = d.in_out[i];
+    std::string p = "downs." + std::to_string(i) + ".";
+    spec_convnext(L, p + "0.", ci, co, d.td, c.convnext_mult);
+    spec_convnext(L, p + "1.", co, co, d.td, c.convnext_mult);
+    spec_attn(L, p + "2.", co, true);
+    if (i < n - 1) { L.add(p + "3.weight", {co, co, 4, 4}); L.add(p + "3.bias", {co}); }
+  }
+  const int mid = d.dims.back();
+  spec_convnext(L, "mid_block1.", mid, mid, d.td, c.convnext_mult);
+  spec_attn(L, "mid_attn.", mid, false);
+  spec_convnext(L, "mid_block2.", mid, mid, d.td, c.convnext_mult);
+  for (int j = 0; j < n - 1; ++j) {
+    auto [ci, co] = d.in_out[n - 1 - j];
+    std::string p = "ups." + std::to_string(j) + ".";
+    spec_convnext(L, p + "0.", co * 2, ci, d.td, c.convnext_mult);
+    spec_convnext(L, p + "1.", ci, ci, d.td, c.convnext_mult);
+    spec_attn(L, p + "2.", ci, true);
+    L.add(p + "3.weight", {ci, ci, 4, 4}); L.add(p + "3.bias", {ci});
+  }
+  spec_convnext(L, "final_conv.0.", c.dim, c.dim, 0, c.convnext_mult);
+  L.add("final_conv.1.weight", {d.out_dim, c.dim, 1, 1}); L.add("final_conv.1.bias", {d.out_dim});
+  return L.v;
+}
+
+std::vector<TensorSpec> resdec_tensor_specs(const ResDecCfg& c) {
+  SpecList L;
+  int init = c.size_in;
+  for (int i = 0; i < c.n_enc; ++i) init /= c.enc[i][3];
+  const int clast = c.enc[c.n_enc - 1][2];
+  L.add("z_lin.weight", {(int64_t)init * init * clast, c.size_z}); L.add("z_lin.bias", {(int64_t)init * init * clast});
+  for (int i = 0; i < c.n_dec; ++i)
+    spec_rblock(L, "dec.r_blocks." + std::to_string(i) + ".", c.dec[i][0], c.dec[i][1], c.dec[i][2]);
+  const int cc = c.dec[c.n_dec - 1][2];
+  spec_rblock(L, "dec.ch_dec.0.", cc, cc, cc);
+  L.add("dec.ch_dec.1.weight", {c.img_ch, cc, 5, 5}); L.add("dec.ch_dec.1.bias", {c.img_ch});
+  return L.v;
+}
+
+static const int kAttrW[5] = {512, 512, 512, 256, 128};
+
+std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& c) {
+  SpecList L;
+  int prev = c.size_z;
+  for (int i = 0; i < 5; ++i) {
+    std::string l = "dec_net." + std::to_string(3 * i) + ".", b = "dec_net." + std::to_string(3 * i + 1) + ".";
+    L.add(l + "weight", {kAttrW[i], prev}); L.add(l + "bias", {kAttrW[i]});
+    L.add(b + "weight", {kAttrW[i]}); L.add(b + "bias", {kAttrW[i]});
+    L.add(b + "running_mean", {kAttrW[i]}); L.add(b + "running_var", {kAttrW[i]});
+    prev = kAttrW[i];
+  }
+  L.add("dec_net.15.weight", {c.att_size, prev}); L.add("dec_net.15.bias", {c.att_size});
+  return L.v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// builder
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// reference channel index -> channel index inside a (possibly concatenated, padded) buffer view
+struct ChanMap {
+  std::vector<int> idx;
+  static ChanMap identity(int c) { ChanMap m; m.idx.resize(c); for (int i = 0; i < c; ++i) m.idx[i] = i; return m; }
+  static ChanMap concat(int c0, int c0pad, int c1) {
+    ChanMap m; m.idx.resize(c0 + c1);
+    for (int i = 0; i < c0; ++i) m.idx[i] = i;
+    for (int i = 0; i < c1; ++i) m.idx[c0 + i] = c0pad + i;
+    return m;
+  }
+  bool is_identity() const { for (size_t i = 0; i < idx.size(); ++i) if (idx[i] != (int)i) return false; return true; }
+  int n() const { return (int)idx.size(); }
+};
+
+struct Block { int64_t off, n; };
+
+class Builder {
+ public:
+  Builder(Plan* p, int B, const std::vector<TensorSpec>& specs, const float* const* tensors) : plan(p), B(B) {
+    plan->B = B;
+    for (size_t i = 0; i < specs.size(); ++i) { index[specs[i].name] = (int)i; this->specs = &specs; }
+    this->tensors = tensors;
+  }
+  Plan* plan; int B;
+  const std::vector<TensorSpec>* specs = nullptr;
+  const float* const* tensors = nullptr;
+  std::map<std::string, int> index;
+  std::vector<Block> free_list;
+
+  const float* T(const std::string& name, int64_t expect_numel = -1) const {
+    auto it = index.find(name);
+    if (it == index.end()) throw std::runtime_error("plan: missing tensor " + name);
+    if (expect_numel >= 0 && (*specs)[it->second].numel() != expect_numel)
+      throw std::runtime_error("plan: tensor " + name + " has unexpected size");
+    const float* p = tensors[it->second];
+    if (!p) throw std::runtime_error("plan: null pointer for tensor " + name);
+    return p;
+  }
+  bool has(const std::string& name) const { return index.count(name) != 0; }
+
+  // ---- params arena (16-byte aligned blocks) ----
+  int64_t add_params(const std::vector<float>& v) {
+    int64_t off = (int64_t)plan->params.size();
+    plan->params.insert(plan->params.end(), v.begin(), v.end());
+    while (plan->params.size() % 4) plan->params.push_back(0.f);
+    return off;
+  }
+
+  // ---- workspace allocator: first-fit free list, blocks rounded to 64 floats (256 B) ----
+  int64_t ws_alloc(int64_t n) {
+    n = (n + 63) / 64 * 64;
+    for (size_t i = 0; i < free_list.size(); ++i) {
+      if (free_list[i].n >= n) {
+        int64_t off = free_list[i].off;
+        free_list[i].off += n; free_list[i].n -= n;
+        if (free_list[i].n == 0) free_list.erase(free_list.begin() + i);
+        sizes[off] = n;
+        return off;
+      }
+    }
+    int64_t off = plan->ws_floats;
+    plan->ws_floats += n;
+    sizes[off] = n;
+    return off;
+  }
+  void ws_free(int64_t off) {
+    auto it = sizes.find(off);
+    if (it == sizes.end()) throw std::runtime_error("plan: double free");
+    Block b{off, it->second};
+    sizes.erase(it);
+    // insert sorted + coalesce
+    auto pos = std::lower_bound(free_list.begin(), free_list.end(), b, [](const Block& x, const Block& y) { return x.off < y.off; });
+    pos = free_list.insert(pos, b);
+    size_t i = pos - free_list.begin();
+    if (i + 1 < free_list.size() && free_list[i].off + free_list[i].n == free_list[i + 1].off) {
+      free_list[i].n += free_list[i + 1].n; free_list.erase(free_list.begin() + i + 1);
+    }
+    if (i > 0 && free_list[i - 1].off + free_list[i - 1].n == free_list[i].off) {
+      free_list[i - 1].n += free_list[i].n; free_list.erase(free_list.begin() + i);
+    }
+  }
+  std::map<int64_t, int64_t> sizes;
+
+  View new_act(int H, int W, int C) {
+    View v; v.H = H; v.W = W; v.C = pad8(C); v.ld = v.C;
+    v.off = ws_alloc((int64_t)H * W * B * v.ld);
+    return v;
+  }
+  void free_act(const View& v) { ws_free(v.off); }
+  int64_t new_stats(int nparts) { return ws_alloc((int64_t)nparts * B * 2); }
+
+  // ---- tile choice ----
+  static void choose_tile(int B, int P, int nstore, int* BM, int* BN) {
+    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    for (auto& c : cand) {
+      if (c[1] > 64 && nstore <= 64) continue;
+      if (c[0] > 64 && B <= 64) continue;
+      long blocks = (long)P * ceil_div(B, c[0]) * ceil_div(nstore, c[1]);
+      if (blocks >= 384) { *BM = c[0]; *BN = c[1]; return; }
+    }
+    *BM = 64; *BN = 64;
+  }
+
+  // ---- weight packing ----
+  // conv weight [Cout][Cin][KH][KW] (or transposed-conv [Cin][Cout][KH][KW]) -> [tap][Npad][Ca]
+  std::vector<float> pack_conv(const float* w, int cout, int cin, int kh, int kw, const ChanMap& cm, int Ca, int Npad,
+                               bool transposed, const std::vector<double>* out_scale = nullptr) {
+    std::vector<float> o((size_t)kh * kw * Npad * Ca, 0.f);
+    for (int n = 0; n < cout; ++n)
+      for (int c = 0; c < cin; ++c)
+        for (int t = 0; t < kh * kw; ++t) {
+          size_t src = transposed ? (((size_t)c * cout + n) * kh * kw + t) : (((size_t)n * cin + c) * kh * kw + t);
+          double v = w[src];
+          if (out_scale) v *= (*out_scale)[n];
+          o[((size_t)t * Npad + n) * Ca + cm.idx[c]] = (float)v;
+        }
+    return o;
+  }
+  std::vector<float> pack_vec(const float* v, int n, const ChanMap* cm, int npad) {
+    std::vector<float> o(npad, 0.f);
+    for (int i = 0; i < n; ++i) o[cm ? cm->idx[i] : i] = v[i];
+    return o;
+  }
+
+  // ---- op emission helpers ----
+  Op& push(int kind, const std::string& name) {
+    plan->ops.emplace_back();
+    plan->ops.back().kind = kind; plan->ops.back().name = name;
+    return plan->ops.back();
+  }
+
+  struct ConvSpec {
+    std::string name;
+    View a; ChanMap cm; int cin_true = 0;
+    int up = 1, kh = 1, kw = 1, stride = 1, pad = 0; bool transposed = false;
+    const float* w = nullptr; const float* bias = nullptr;
+    int cout = 0;
+    int Hout = 1, Wout = 1;
+    // GN on load
+    bool gn = false; int64_t gn_part = 0; int gn_nparts = 0; float gn_inv = 0; const float* gamma = nullptr; const float* beta = nullptr;
+    // source 2
+    bool has2 = false; View a2; ChanMap cm2; const float* w2 = nullptr; const float* bias2 = nullptr; int cin2 = 0; int up2 = 1;
+    bool has_res = false; View r;
+    int act = ACT_NONE;
+    bool want_stats = false;
+    bool out_nchw = false; int crop_y = 0, crop_x = 0, Hn = 0, Wn = 0;
+    const std::vector<double>* out_scale = nullptr;     // BN fold: per-output-channel scale on w
+    const std::vector<double>* out_shift = nullptr;     // BN fold: replaces / adds to bias
+    View* dest = nullptr;    // write into this existing view instead of a fresh tensor
+  };
+
+  struct ConvResult { View out; int64_t stat_off = -1; int stat_nparts = 0; };
+
+  ConvResult emit_conv(const ConvSpec& s) {
+    Op& op = push(OP_GEMM, s.name);
+    GemmOp& g = op.g;
+    g.B = B; g.Hout = s.Hout; g.Wout = s.Wout;
+    g.a = s.a; g.up = s.up; g.KH = s.kh; g.KW = s.kw; g.stride = s.stride; g.pad = s.pad; g.transposed = s.transposed;
+    g.N = s.cout;
+    const int nstore = s.out_nchw ? s.cout : pad8(s.cout);
+    g.Npad = round_up(nstore, 32);
+    g.w_off = add_params(pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, s.a.C, g.Npad, s.transposed, s.out_scale));
+    std::vector<double> bias(g.Npad, 0.0);
+    bool any_bias = false;
+    if (s.bias) { for (int n = 0; n < s.cout; ++n) bias[n] += (s.out_scale ? (*s.out_scale)[n] : 1.0) * s.bias[n]; any_bias = true; }
+    if (s.out_shift) { for (int n = 0; n < s.cout; ++n) bias[n] += (*s.out_shift)[n]; any_bias = true; }
+    if (s.gn) {
+      g.gn = 1; g.gn_part_off = s.gn_part; g.gn_nparts = s.gn_nparts; g.gn_inv_count = s.gn_inv;
+      g.gn_gamma_off = add_params(pack_vec(s.gamma, s.cin_true, &s.cm, s.a.C));
+      g.gn_beta_off = add_params(pack_vec(s.beta, s.cin_true, &s.cm, s.a.C));
+    }
+    if (s.has2) {
+      g.has2 = 1; g.a2 = s.a2; g.up2 = s.up2;
+      g.w2_off = add_params(pack_conv(s.w2, s.cout, s.cin2, 1, 1, s.cm2, s.a2.C, g.Npad, false, nullptr));
+      if (s.bias2) { for (int n = 0; n < s.cout; ++n) bias[n] += s.bias2[n]; any_bias = true; }
+    }
+    if (any_bias) { std::vector<float> bf(bias.begin(), bias.end()); g.bias_off = add_params(bf); }
+    if (s.has_res) { g.has_res = 1; g.r = s.r; g.up2 = s.up2; }
+    g.act = s.act;
+    const int P = s.Hout * s.Wout;
+    choose_tile(B, P, nstore, &g.BM, &g.BN);
+    ConvResult res;
+    if (s.out_nchw) {
+      g.out_nchw = 1; g.crop_y = s.crop_y; g.crop_x = s.crop_x; g.Hn = s.Hn; g.Wn = s.Wn;
+      g.out.C = s.cout; g.out.H = s.Hout; g.out.W = s.Wout;
+    } else {
+      g.out = s.dest ? *s.dest : new_act(s.Hout, s.Wout, s.cout);
+      res.out = g.out;
+    }
+    if (s.want_stats) {
+      const int ntiles = ceil_div(nstore, g.BN);
+      res.stat_nparts = P * ntiles;
+      res.stat_off = g.stat_off = new_stats(res.stat_nparts);
+    }
+    // flop accounting
+    double taps_valid = 0;
+    for (int oy = 0; oy < s.Hout; ++oy) for (int ox = 0; ox < s.Wout; ++ox)
+      for (int ky = 0; ky < s.kh; ++ky) for (int kx = 0; kx < s.kw; ++kx) {
+        int iy, ix; bool ok;
+        const int Hs = s.a.H * s.up, Ws = s.a.W * s.up;
+        if (!s.transposed) { iy = oy * s.stride - s.pad + ky; ix = ox * s.stride - s.pad + kx; ok = iy >= 0 && iy < Hs && ix >= 0 && ix < Ws; }
+        else { int ny = oy + s.pad - ky, nx = ox + s.pad - kx; ok = ny >= 0 && nx >= 0 && ny % s.stride == 0 && nx % s.stride == 0 && ny / s.stride < Hs && nx / s.stride < Ws; }
+        taps_valid += ok ? 1 : 0;
+      }
+    double dense_taps = s.transposed ? (double)s.a.H * s.a.W * s.kh * s.kw : (double)P * s.kh * s.kw;
+    plan->flops_dense += 2.0 * B * s.cout * (dense_taps * s.cin_true + (s.has2 ? (double)P * s.cin2 : 0.0));
+    plan->flops_exec += 2.0 * B * g.Npad * (taps_valid * s.a.C + (s.has2 ? (double)P * s.a2.C : 0.0));
+    return res;
+  }
+};
+
+// ConvNeXt block (unet_model.py:92-124).  `x` is the block input view with channel map `cm`.
+struct BlockIO { View out; int64_t stat_off = -1; int stat_nparts = 0; };
+
+BlockIO emit_convnext(Builder& b, const std::string& pre, const View& x, const ChanMap& cm, int cin, int cout, int mult,
+                      bool has_time, int64_t cond_off, int cond_ld, bool want_out_stats, View* dest) {
+  const int H = x.H, W = x.W, P = H * W;
+  // depthwise 7x7 + bias + time condition -> h0, GroupNorm partials
+  View h0; h0.H = H; h0.W = W; h0.C = x.C; h0.ld = x.C; h0.off = b.ws_alloc((int64_t)P * b.B * h0.ld);
+  int64_t st0 = b.new_stats(P);
+  {
+    Op& op = b.push(OP_DWCONV7, pre + "ds_conv");
+    DwOp& d = op.dw; d.B = b.B; d.in = x; d.out = h0;
+    const float* w = b.T(pre + "ds_conv.weight", (int64_t)cin * 49);
+    std::vector<float> wp((size_t)49 * x.C, 0.f);
+    for (int c = 0; c < cin; ++c) for (int t = 0; t < 49; ++t) wp[(size_t)t * x.C + cm.idx[c]] = w[(size_t)c * 49 + t];
+    d.w_off = b.add_params(wp);
+    d.bias_off = b.add_params(b.pack_vec(b.T(pre + "ds_conv.bias", cin), cin, &cm, x.C));
+    d.has_cond = has_time ? 1 : 0; d.cond_off = cond_off; d.cond_ld = cond_ld;
+    d.stat_off = st0;
+    b.plan->flops_dense += 2.0 * b.B * cin * 49.0 * P;
+    b.plan->flops_exec += 2.0 * b.B * x.C * 49.0 * P;
+  }
+  // GN -> conv3x3 -> GELU  (net.0, net.1, net.2)
+  Builder::ConvSpec c1;
+  c1.name = pre + "net.1"; c1.a = h0; c1.cm = cm; c1.cin_true = cin; c1.kh = c1.kw = 3; c1.pad = 1;
+  c1.w = b.T(pre + "net.1.weight", (int64_t)cout * mult * cin * 9); c1.bias = b.T(pre + "net.1.bias", cout * mult);
+  c1.cout = cout * mult; c1.Hout = H; c1.Wout = W;
+  c1.gn = true; c1.gn_part = st0; c1.gn_nparts = P; c1.gn_inv = 1.0f / ((float)cin * P);
+  c1.gamma = b.T(pre + "net.0.weight", cin); c1.beta = b.T(pre + "net.0.bias", cin);
+  c1.act = ACT_GELU; c1.want_stats = true;
+  Builder::ConvResult r1 = b.emit_conv(c1);
+  b.ws_free(st0); b.free_act(h0);
+  // GN -> conv3x3 (+ res)  (net.3, net.4, res_conv)
+  Builder::ConvSpec c2;
+  c2.name = pre + "net.4"; c2.a = r1.out; c2.cm = ChanMap::identity(cout * mult); c2.cin_true = cout * mult; c2.kh = c2.kw = 3; c2.pad = 1;
+  c2.w = b.T(pre + "net.4.weight", (int64_t)cout * cout * mult * 9); c2.bias = b.T(pre + "net.4.bias", cout);
+  c2.cout = cout; c2.Hout = H; c2.Wout = W;
+  c2.gn = true; c2.gn_part = r1.stat_off; c2.gn_nparts = r1.stat_nparts; c2.gn_inv = 1.0f / ((float)cout * mult * P);
+  c2.gamma = b.T(pre + "net.3.weight", cout * mult); c2.beta = b.T(pre + "net.3.bias", cout * mult);
+  if (cin != cout) {
+    c2.has2 = true; c2.a2 = x; c2.cm2 = cm; c2.cin2 = cin;
+    c2.w2 = b.T(pre + "res_conv.weight", (int64_t)cout * cin); c2.bias2 = b.T(pre + "res_conv.bias", cout);
+  } else {
+    if (!cm.is_identity()) throw std::runtime_error("plan: identity residual over a padded concat");
+    c2.has_res = true; c2.r = x;
+  }
+  c2.want_stats = want_out_stats; c2.dest = dest;
+  Builder::ConvResult r2 = b.emit_conv(c2);
+  b.ws_free(r1.stat_off); b.free_act(r1.out);
+  BlockIO io; io.out = r2.out; io.stat_off = r2.stat_off; io.stat_nparts = r2.stat_nparts;
+  return io;
+}
+
+// Residual(PreNorm(c, LinearAttention(c))) / Residual(PreNorm(c, Attention(c)))  (unet_model.py:126-187)
+// x must carry GroupNorm partials (stat_off).  Result written to *dest (or a fresh tensor).
+View emit_attention(Builder& b, const std::string& pre, const View& x, int c, int64_t x_stat, int x_nparts, bool linear, View* dest) {
+  const int H = x.H, W = x.W, P = H * W, hid = 128;
+  Builder::ConvSpec q;
+  q.name = pre + "fn.fn.to_qkv"; q.a = x; q.cm = ChanMap::identity(c); q.cin_true = c;
+  q.w = b.T(pre + "fn.fn.to_qkv.weight", (int64_t)3 * hid * c); q.cout = 3 * hid; q.Hout = H; q.Wout = W;
+  q.gn = true; q.gn_part = x_stat; q.gn_nparts = x_nparts; q.gn_inv = 1.0f / ((float)c * P);
+  q.gamma = b.T(pre + "fn.norm.weight", c); q.beta = b.T(pre + "fn.norm.bias", c);
+  Builder::ConvResult rq = b.emit_conv(q);
+  View att = b.new_act(H, W, hid);
+  {
+    Op& op = b.push(linear ? OP_LINATTN : OP_ATTN, pre + "fn.fn.core");
+    AttnOp& a = op.at; a.B = b.B; a.qkv = rq.out; a.out = att; a.heads = 4; a.dh = 32; a.scale = 1.0f / std::sqrt(32.0f);
+    b.plan->flops_dense += 2.0 * b.B * 4 * (linear ? 2.0 * 32 * 32 * P : 2.0 * 32 * (double)P * P);
+    b.plan->flops_exec += 2.0 * b.B * 4 * (linear ? 2.0 * 32 * 32 * P : 2.0 * 32 * (double)P * P);
+  }
+  b.free_act(rq.out);
+  View out;
+  if (linear) {
+    Builder::ConvSpec o;
+    o.name = pre + "fn.fn.to_out.0"; o.a = att; o.cm = ChanMap::identity(hid); o.cin_true = hid;
+    o.w = b.T(pre + "fn.fn.to_out.0.weight", (int64_t)c * hid); o.bias = b.T(pre + "fn.fn.to_out.0.bias", c);
+    o.cout = c; o.Hout = H; o.Wout = W; o.want_stats = true;
+    Builder::ConvResult ro = b.emit_conv(o);
+    out = dest ? *dest : b.new_act(H, W, c);
+    Op& op = b.push(OP_GN_RES, pre + "fn.fn.to_out.1+residual");
+    GnResOp& g = op.gr; g.B = b.B; g.u = ro.out; g.x = x; g.out = out;
+    g.part_off = ro.stat_off; g.nparts = ro.stat_nparts; g.inv_count = 1.0f / ((float)c * P);
+    g.gamma_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.weight", c), c, nullptr, x.C));
+    g.beta_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.bias", c), c, nullptr, x.C));
+    b.ws_free(ro.stat_off); b.free_act(ro.out);
+  } else {
+    Builder::ConvSpec o;
+    o.name = pre + "fn.fn.to_out"; o.a = att; o.cm = ChanMap::identity(hid); o.cin_true = hid;
+    o.w = b.T(pre + "fn.fn.to_out.weight", (int64_t)c * hid); o.bias = b.T(pre + "fn.fn.to_out.bias", c);
+    o.cout = c; o.Hout = H; o.Wout = W; o.has_res = true; o.r = x; o.dest = dest;
+    out = b.emit_conv(o).out;
+  }
+  b.free_act(att);
+  return out;
+}
+
+int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+}  // namespace
+
+bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Plan* plan) {
+  try {
+    std::vector<TensorSpec> specs = unet_tensor_specs(cfg);
+    Builder b(plan, B, specs, tensors);
+    UnetDims d = unet_dims(cfg);
+    const int n = (int)d.in_out.size();
+    const int Hp = next_pow2(cfg.H), Wp = next_pow2(cfg.W);       // unet_model.py:276-284
+    const int pad_y = (Hp - cfg.H) / 2, pad_x = (Wp - cfg.W) / 2;
+    if ((Hp >> (n - 1)) < 1 || (Wp >> (n - 1)) < 1) throw std::runtime_error("plan: input too small for the UNet depth");
+    plan->in_C = cfg.channels; plan->in_H = cfg.H; plan->in_W = cfg.W;
+    plan->out_C = d.out_dim; plan->out_H = cfg.H; plan->out_W = cfg.W;
+    plan->needs_time = d.td ? 1 : 0;
+
+    // external NCHW input -> PBC
+    View xin = b.new_act(Hp, Wp, cfg.channels);
+    { Op& op = b.push(OP_NCHW_TO_PBC, "input"); op.cv.B = B; op.cv.C = cfg.channels; op.cv.Hn = cfg.H; op.cv.Wn = cfg.W; op.cv.pad_y = pad_y; op.cv.pad_x = pad_x; op.cv.out = xin; }
+
+    // time path: sinusoid -> Linear -> GELU -> Linear (-> GELU, shared first op of every block mlp) -> all block Linears
+    struct TB { std::string pre; int width; };      // width = channel count of the block's input view
+    std::vector<TB> tblocks;
+    if (d.td) {
+      for (int i = 0; i < n; ++i) { tblocks.push_back({"downs." + std::to_string(i) + ".0.", pad8(d.in_out[i].first)}); tblocks.push_back({"downs." + std::to_string(i) + ".1.", pad8(d.in_out[i].second)}); }
+      tblocks.push_back({"mid_block1.", pad8(d.dims.back())}); tblocks.push_back({"mid_block2.", pad8(d.dims.back())});
+      for (int j = 0; j < n - 1; ++j) { auto [ci, co] = d.in_out[n - 1 - j]; tblocks.push_back({"ups." + std::to_string(j) + ".0.", 2 * pad8(co)}); tblocks.push_back({"ups." + std::to_string(j) + ".1.", pad8(ci)}); }
+    }
+    std::map<std::string, int> cond_col;
+    int cond_ld = 0;
+    int64_t cond_off = 0;
+    View cond_all;
+    if (d.td) {
+      plan->time_off = b.ws_alloc(B);
+      View e0 = b.new_act(1, 1, cfg.dim);
+      {
+        // unet_model.py:42-44: freqs = exp(arange(half) * -(log(1e4)/(half-1))) in fp32
+        Op& op = b.push(OP_SINUS, "time_mlp.0"); op.si.B = B; op.si.dim = cfg.dim; op.si.out_off = e0.off; op.si.ld = e0.ld;
+        const int half = cfg.dim / 2;
+        std::vector<float> fr(half);
+        const float k = (float)(-(std::log(10000.0) / (half - 1)));
+        for (int j = 0; j < half; ++j) { float arg = (float)j * k; fr[j] = (float)std::exp((double)arg); }
+        op.si.freq_off = b.add_params(fr);
+      }
+      Builder::ConvSpec l1; l1.name = "time_mlp.1"; l1.a = e0; l1.cm = ChanMap::identity(cfg.dim); l1.cin_true = cfg.dim;
+      l1.w = b.T("time_mlp.1.weight", (int64_t)d.td * cfg.dim); l1.bias = b.T("time_mlp.1.bias", d.td); l1.cout = d.td; l1.act = ACT_GELU;
+      View e1 = b.emit_conv(l1).out;
+      Builder::ConvSpec l2; l2.name = "time_mlp.3(+GELU of every block mlp)"; l2.a = e1; l2.cm = ChanMap::identity(d.td); l2.cin_true = d.td;
+      l2.w = b.T("time_mlp.3.weight", (int64_t)d.td * d.td); l2.bias = b.T("time_mlp.3.bias", d.td); l2.cout = d.td; l2.act = ACT_GELU;
+      View e2 = b.emit_conv(l2).out;
+      b.free_act(e0); b.free_act(e1);
+      // every ConvNextBlock.mlp Linear as one GEMM; column ranges follow the channel layout of each block's input
+      int col = 0;
+      for (auto& tb : tblocks) { cond_col[tb.pre] = col; col += tb.width; }
+      cond_ld = round_up(col, 8);
+      // weights are filled in during the walk (they need each block's channel map) and attached at the end
+      cond_all = b.new_act(1, 1, cond_ld);
+      cond_off = cond_all.off;
+      // placeholder op; weights patched in after the walk (needs the concat channel maps)
+      Op& op = b.push(OP_GEMM, "convnext mlp.1 (all blocks)");
+      GemmOp& g = op.g; g.B = B; g.a = e2; g.N = cond_ld; g.Npad = round_up(cond_ld, 32); g.out = cond_all;
+      Builder::choose_tile(B, 1, cond_ld, &g.BM, &g.BN);
+      plan->flops_exec += 2.0 * B * g.Npad * d.td;
+      b.free_act(e2);   // ops run in stream order: e2 is dead once the GEMM above has executed
+    }
+    const size_t cond_op_index = plan->ops.size() - 1;
+    std::vector<float> cond_w, cond_b;
+    if (d.td) { cond_w.assign((size_t)round_up(cond_ld, 32) * d.td, 0.f); cond_b.assign(round_up(cond_ld, 32), 0.f); }
+    auto add_cond = [&](const std::string& pre, int cin, const ChanMap& cm) {
+      if (!d.td) return;
+      const float* w = b.T(pre + "mlp.1.weight", (int64_t)cin * d.td);
+      const float* bb = b.T(pre + "mlp.1.bias", cin);
+      const int col = cond_col.at(pre);
+      for (int c = 0; c < cin; ++c) {
+        std::memcpy(&cond_w[(size_t)(col + cm.idx[c]) * d.td], &w[(size_t)c * d.td], sizeof(float) * d.td);
+        cond_b[col + cm.idx[c]] = bb[c];
+      }
+      plan->flops_dense += 2.0 * B * cin * d.td;
+    };
+
+    // init conv 7x7
+    Builder::ConvSpec ic; ic.name = "init_conv"; ic.a = xin; ic.cm = ChanMap::identity(cfg.channels); ic.cin_true = cfg.channels;
+    ic.kh = ic.kw = 7; ic.pad = 3; ic.w = b.T("init_conv.weight", (int64_t)d.init_dim * cfg.channels * 49); ic.bias = b.T("init_conv.bias", d.init_dim);
+    ic.cout = d.init_dim; ic.Hout = Hp; ic.Wout = Wp;
+    View x = b.emit_conv(ic).out;
+    b.free_act(xin);
+
+    // down path.  Level i>=1 writes its skip tensor straight into the second half of the concat
+    // buffer its up level will read (torch.cat((x, h.pop()), dim=1), unet_model.py:311).
+    std::vector<View> cat(n);       // cat[i]: concat buffer for the up level that pops h_i  (i >= 1)
+    std::vector<View> skip(n);
+    int H = Hp, W = Wp;
+    for (int i = 0; i < n; ++i) {
+      auto [ci, co] = d.in_out[i];
+      std::string p = "downs." + std::to_string(i) + ".";
+      ChanMap cmi = ChanMap::identity(ci);
+      add_cond(p + "0.", ci, cmi);
+      BlockIO b1 = emit_convnext(b, p + "0.", x, cmi, ci, co, cfg.convnext_mult, d.td != 0, cond_off + (d.td ? cond_col[p + "0."] : 0), cond_ld, false, nullptr);
+      b.free_act(x);
+      ChanMap cmo = ChanMap::identity(co);
+      add_cond(p + "1.", co, cmo);
+      BlockIO b2 = emit_convnext(b, p + "1.", b1.out, cmo, co, co, cfg.convnext_mult, d.td != 0, cond_off + (d.td ? cond_col[p + "1."] : 0), cond_ld, true, nullptr);
+      b.free_act(b1.out);
+      View dest; View* dp = nullptr;
+      if (i >= 1) {
+        // concat buffer [x_up (co) | h_i (co)], both padded to 8
+        View cb; cb.H = H; cb.W = W; cb.C = 2 * pad8(co); cb.ld = cb.C; cb.off = b.ws_alloc((int64_t)H * W * B * cb.ld);
+        cat[i] = cb;
+        dest = cb; dest.off = cb.off + pad8(co); dest.C = pad8(co);
+        dp = &dest;
+      }
+      View y = emit_attention(b, p + "2.", b2.out, co, b2.stat_off, b2.stat_nparts, true, dp);
+      b.ws_free(b2.stat_off); b.free_act(b2.out);
+      skip[i] = y;
+      if (i < n - 1) {
+        Builder::ConvSpec ds; ds.name = p + "3"; ds.a = y; ds.cm = ChanMap::identity(co); ds.cin_true = co; ds.kh = ds.kw = 4; ds.stride = 2; ds.pad = 1;
+        ds.w = b.T(p + "3.weight", (int64_t)co * co * 16); ds.bias = b.T(p + "3.bias", co); ds.cout = co; ds.Hout = H / 2; ds.Wout = W / 2;
+        x = b.emit_conv(ds).out;
+        H /= 2; W /= 2;
+        if (i == 0) b.free_act(y);      // h_0 is never popped (unet_model.py:244-262: only n-1 up levels)
+      } else {
+        x = y;                          // last level: Identity instead of Downsample; x aliases the concat half
+      }
+    }
+    // bottleneck.  x is skip[n-1], which lives in cat[n-1]'s second half when n >= 2.
+    const int mid = d.dims.back();
+    ChanMap cmm = ChanMap::identity(mid);
+    add_cond("mid_block1.", mid, cmm);
+    BlockIO m1 = emit_convnext(b, "mid_block1.", x, cmm, mid, mid, cfg.convnext_mult, d.td != 0, cond_off + (d.td ? cond_col["mid_block1."] : 0), cond_ld, true, nullptr);
+    if (n == 1) b.free_act(x);
+    View ma = emit_attention(b, "mid_attn.", m1.out, mid, m1.stat_off, m1.stat_nparts, false, nullptr);
+    b.ws_free(m1.stat_off); b.free_act(m1.out);
+    add_cond("mid_block2.", mid, cmm);
+    View up_dest; View* udp = nullptr;
+    if (n >= 2) { up_dest = cat[n - 1]; up_dest.C = pad8(mid); udp = &up_dest; }
+    BlockIO m2 = emit_convnext(b, "mid_block2.", ma, cmm, mid, mid, cfg.convnext_mult, d.td != 0, cond_off + (d.td ? cond_col["mid_block2."] : 0), cond_ld, false, udp);
+    b.free_act(ma);
+    x = m2.out;
+    // up path
+    for (int j = 0; j < n - 1; ++j) {
+      auto [ci, co] = d.in_out[n - 1 - j];
+      std::string p = "ups." + std::to_string(j) + ".";
+      View cb = cat[n - 1 - j];
+      ChanMap cmc = ChanMap::concat(co, pad8(co), co);
+      add_cond(p + "0.", co * 2, cmc);
+      BlockIO b1 = emit_convnext(b, p + "0.", cb, cmc, co * 2, ci, cfg.convnext_mult, d.td != 0, cond_off + (d.td ? cond_col[p + "0."] : 0), cond_ld, false, nullptr);
+      b.ws_free(cb.off);
+      ChanMap cmi = ChanMap::identity(ci);
+      add_cond(p + "1.", ci, cmi);
+      BlockIO b2 = emit_convnext(b, p + "1.", b1.out, cmi, ci, ci, cfg.convnext_mult, d.td != 0, cond_off + (d.td ? cond_col[p + "1."] : 0), cond_ld, true, nullptr);
+      b.free_act(b1.out);
+      View y = emit_attention(b, p + "2.", b2.out, ci, b2.stat_off, b2.stat_nparts, true, nullptr);
+      b.ws_free(b2.stat_off); b.free_act(b2.out);
+      // Upsample = ConvTranspose2d(ci, ci, 4, 2, 1) -> first half of the next concat buffer (or a plain tensor)
+      Builder::ConvSpec us; us.name = p + "3"; us.a = y; us.cm = ChanMap::identity(ci); us.cin_true = ci; us.kh = us.kw = 4; us.stride = 2; us.pad = 1; us.transposed = true;
+      us.w = b.T(p + "3.weight", (int64_t)ci * ci * 16); us.bias = b.T(p + "3.bias", ci); us.cout = ci; us.Hout = H * 2; us.Wout = W * 2;
+      View ud;
+      if (j + 1 < n - 1) { ud = cat[n - 2 - j]; ud.C = pad8(ci); us.dest = &ud; }
+      x = b.emit_conv(us).out;
+      b.free_act(y);
+      H *= 2; W *= 2;
+    }
+    // final_conv = ConvNextBlock(dim, dim) (no time) + 1x1 conv -> NCHW score (unet_model.py:270-272)
+    if (x.C != pad8(cfg.dim)) throw std::runtime_error("plan: final_conv expects `dim` channels (dim_mults[0] must be 1)");
+    BlockIO f = emit_convnext(b, "final_conv.0.", x, ChanMap::identity(cfg.dim), cfg.dim, cfg.dim, cfg.convnext_mult, false, 0, 0, false, nullptr);
+    b.free_act(x);
+    Builder::ConvSpec fc; fc.name = "final_conv.1"; fc.a = f.out; fc.cm = ChanMap::identity(cfg.dim); fc.cin_true = cfg.dim;
+    fc.w = b.T("final_conv.1.weight", (int64_t)d.out_dim * cfg.dim); fc.bias = b.T("final_conv.1.bias", d.out_dim);
+    fc.cout = d.out_dim; fc.Hout = H; fc.Wout = W; fc.out_nchw = true; fc.crop_y = pad_y; fc.crop_x = pad_x; fc.Hn = cfg.H; fc.Wn = cfg.W;
+    b.emit_conv(fc);
+    b.free_act(f.out);
+    // patch the concatenated mlp weights
+    if (d.td) {
+      GemmOp& g = plan->ops[cond_op_index].g;
+      g.w_off = b.add_params(cond_w);
+      g.bias_off = b.add_params(cond_b);
+    }
+    return true;
+  } catch (const std::exception& e) {
+    plan->error = e.what();
+    return false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoders
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+// BatchNorm(eval) folded into the preceding bias-free conv / Linear: y = conv * s + (beta - mean * s)
+void bn_fold(const Builder& b, const std::string& pre, int c, std::vector<double>* scale, std::vector<double>* shift) {
+  const float* w = b.T(pre + "weight", c); const float* bi = b.T(pre + "bias", c);
+  const float* rm = b.T(pre + "running_mean", c); const float* rv = b.T(pre + "running_var", c);
+  scale->resize(c); shift->resize(c);
+  for (int i = 0; i < c; ++i) {
+    double s = (double)w[i] / std::sqrt((double)rv[i] + 1e-5);
+    (*scale)[i] = s; (*shift)[i] = (double)bi[i] - (double)rm[i] * s;
+  }
+}
+
+// RBlock / RBlockN (h_vae_model_copy.py:9-39, 347-377) with BN folded.  `x` may be a lower-resolution
+// tensor whose nearest upsample (factor up_in) is folded into the reads.
+View emit_rblock(Builder& b, const std::string& pre, const View& x, int up_in, int cin, int cmid, int cout, int act) {
+  const int H = x.H * up_in, W = x.W * up_in;
+  std::vector<double> s1, t1, s2, t2;
+  bn_fold(b, pre + "conv.1.", cmid, &s1, &t1);
+  bn_fold(b, pre + "conv.4.", cout, &s2, &t2);
+  Builder::ConvSpec c1; c1.name = pre + "conv.0+bn+act"; c1.a = x; c1.up = up_in; c1.cm = ChanMap::identity(cin); c1.cin_true = cin; c1.kh = c1.kw = 3; c1.pad = 1;
+  c1.w = b.T(pre + "conv.0.weight", (int64_t)cmid * cin * 9); c1.cout = cmid; c1.Hout = H; c1.Wout = W; c1.out_scale = &s1; c1.out_shift = &t1; c1.act = act;
+  View m = b.emit_conv(c1).out;
+  Builder::ConvSpec c2; c2.name = pre + "conv.3+bn+skip+act"; c2.a = m; c2.cm = ChanMap::identity(cmid); c2.cin_true = cmid; c2.kh = c2.kw = 3; c2.pad = 1;
+  c2.w = b.T(pre + "conv.3.weight", (int64_t)cout * cmid * 9); c2.cout = cout; c2.Hout = H; c2.Wout = W; c2.out_scale = &s2; c2.out_shift = &t2; c2.act = act;
+  c2.up2 = up_in;
+  if (cin != cout) { c2.has2 = true; c2.a2 = x; c2.cm2 = ChanMap::identity(cin); c2.cin2 = cin; c2.w2 = b.T(pre + "size_conv.weight", (int64_t)cout * cin); }
+  else { c2.has_res = true; c2.r = x; }
+  View o = b.emit_conv(c2).out;
+  b.free_act(m);
+  return o;
+}
+
+}  // namespace
+
+bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const* tensors, Plan* plan) {
+  try {
+    std::vector<TensorSpec> specs = resdec_tensor_specs(cfg);
+    Builder b(plan, B, specs, tensors);
+    int init = cfg.size_in;
+    for (int i = 0; i < cfg.n_enc; ++i) init /= cfg.enc[i][3];
+    const int clast = cfg.enc[cfg.n_enc - 1][2];
+    const int P0 = init * init;
+    plan->in_C = cfg.size_z; plan->in_ld = z_ld; plan->in_H = plan->in_W = 1;
+    plan->out_C = cfg.img_ch; plan->out_H = plan->out_W = cfg.size_in;
+    if (cfg.size_z % 4 || z_ld % 4) throw std::runtime_error("plan: latent width / pitch must be a multiple of 4 floats");
+    // z_lin + ReLU, written directly in PBC: weights per output pixel p: W_p[c][k] = z_lin.weight[c*P0 + p][k]
+    // (h_vae_model_copy.py:124-125: relu(z_lin(z)).view(B, C, s, s))
+    View h = b.new_act(init, init, clast);
+    {
+      Op& op = b.push(OP_GEMM, "z_lin+relu");
+      GemmOp& g = op.g; g.B = B; g.Hout = init; g.Wout = init;
+      g.a_ext = 1; g.a_bcast = 1; g.a.C = cfg.size_z; g.a.ld = z_ld; g.a.H = g.a.W = 1; g.a.off = 0;
+      g.N = clast; g.Npad = round_up(pad8(clast), 32);
+      const float* w = b.T("z_lin.weight", (int64_t)P0 * clast * cfg.size_z); const float* bi = b.T("z_lin.bias", (int64_t)P0 * clast);
+      std::vector<float> wp((size_t)P0 * g.Npad * cfg.size_z, 0.f), bp((size_t)P0 * g.Npad, 0.f);
+      for (int p = 0; p < P0; ++p) for (int c = 0; c < clast; ++c) {
+        std::memcpy(&wp[((size_t)p * g.Npad + c) * cfg.size_z], &w[((size_t)c * P0 + p) * cfg.size_z], sizeof(float) * cfg.size_z);
+        bp[(size_t)p * g.Npad + c] = bi[(size_t)c * P0 + p];
+      }
+      g.w_off = b.add_params(wp); g.w_pix_stride = (int64_t)g.Npad * cfg.size_z;
+      g.bias_off = b.add_params(bp); g.bias_pix_stride = g.Npad;
+      g.act = ACT_RELU; g.out = h;
+      Builder::choose_tile(B, P0, pad8(clast), &g.BM, &g.BN);
+      plan->flops_dense += 2.0 * B * P0 * clast * cfg.size_z;
+      plan->flops_exec += 2.0 * B * P0 * g.Npad * cfg.size_z;
+    }
+    const int act = cfg.variant == 0 ? ACT_LRELU02 : ACT_GELU;
+    int up_in = 1;
+    for (int i = 0; i < cfg.n_dec; ++i) {
+      View o = emit_rblock(b, "dec.r_blocks." + std::to_string(i) + ".", h, up_in, cfg.dec[i][0], cfg.dec[i][1], cfg.dec[i][2], act);
+      b.free_act(h);
+      const int up = cfg.dec[i][3];
+      if (cfg.variant == 0) { h = o; up_in = up; }          // nearest: folded into the next reads
+      else {
+        View u = b.new_act(o.H * up, o.W * up, cfg.dec[i][2]);
+        Op& op = b.push(OP_BILINEAR, "dec.r_blocks." + std::to_string(i) + ".up_pool");
+        op.bl.B = B; op.bl.scale = up; op.bl.in = o; op.bl.out = u;
+        b.free_act(o); h = u; up_in = 1;
+      }
+    }
+    const int cc = cfg.dec[cfg.n_dec - 1][2];
+    View o = emit_rblock(b, "dec.ch_dec.0.", h, up_in, cc, cc, cc, ACT_LRELU02);   // plain RBlock in both variants
+    b.free_act(h);
+    Builder::ConvSpec fc; fc.name = "dec.ch_dec.1"; fc.a = o; fc.cm = ChanMap::identity(cc); fc.cin_true = cc; fc.kh = fc.kw = 5; fc.pad = 2;
+    fc.w = b.T("dec.ch_dec.1.weight", (int64_t)cfg.img_ch * cc * 25); fc.bias = b.T("dec.ch_dec.1.bias", cfg.img_ch);
+    fc.cout = cfg.img_ch; fc.Hout = o.H; fc.Wout = o.W; fc.out_nchw = true; fc.Hn = o.H; fc.Wn = o.W;
+    fc.act = cfg.variant == 0 ? ACT_NONE : ACT_SIGMOID;
+    if (o.H != cfg.size_in) throw std::runtime_error("plan: decoder geometry does not reach size_in");
+    b.emit_conv(fc);
+    b.free_act(o);
+    return true;
+  } catch (const std::exception& e) {
+    plan->error = e.what();
+    return false;
+  }
+}
+
+bool build_attrdec_plan(const AttrDecCfg& cfg, int B, int z_ld, const float* const* tensors, Plan* plan) {
+  try {
+    std::vector<TensorSpec> specs = attrdec_tensor_specs(cfg);
+    Builder b(plan, B, specs, tensors);
+    plan->in_C = cfg.size_z; plan->in_ld = z_ld; plan->in_H = plan->in_W = 1;
+    plan->out_C = cfg.att_size; plan->out_H = plan->out_W = 1;
+    if (cfg.size_z % 4 || z_ld % 4) throw std::runtime_error("plan: latent width / pitch must be a multiple of 4 floats");
+    View h; int prev = cfg.size_z;
+    for (int i = 0; i < 5; ++i) {
+      std::string l = "dec_net." + std::to_string(3 * i) + ".", bnp = "dec_net." + std::to_string(3 * i + 1) + ".";
+      std::vector<double> s, t;
+      bn_fold(b, bnp, kAttrW[i], &s, &t);
+      Builder::ConvSpec c; c.name = l + "+bn+relu"; c.cm = ChanMap::identity(prev); c.cin_true = prev;
+      c.w = b.T(l + "weight", (int64_t)kAttrW[i] * prev); c.bias = b.T(l + "bias", kAttrW[i]); c.cout = kAttrW[i];
+      c.out_scale = &s; c.out_shift = &t; c.act = ACT_RELU;
+      if (i == 0) { c.a.C = cfg.size_z; c.a.ld = z_ld; c.a.H = c.a.W = 1; c.a.off = 0; }
+      else c.a = h;
+      Builder::ConvResult r = b.emit_conv(c);
+      if (i == 0) plan->ops.back().g.a_ext = 1;
+      else b.free_act(h);
+      h = r.out; prev = kAttrW[i];
+    }
+    Builder::ConvSpec c; c.name = "dec_net.15"; c.a = h; c.cm = ChanMap::identity(prev); c.cin_true = prev;
+    c.w = b.T("dec_net.15.weight", (int64_t)cfg.att_size * prev); c.bias = b.T("dec_net.15.bias", cfg.att_size); c.cout = cfg.att_size;
+    c.out_nchw = true; c.Hn = c.Wn = 1;
+    b.emit_conv(c);
+    b.free_act(h);
+    return true;
+  } catch (const std::exception& e) {
+    plan->error = e.what();
+    return false;
+  }
+}
+
+}  // namespace sbm
