@@ -1,0 +1,138 @@
+/* sbmae.h -- C ABI of libsbmae_hip.so: the MI355X-native latent score-model sampling path.
+ *
+ * The reference (DanielMitiku/score_based_multimodal_autoencoder) is pure Python/PyTorch and has no
+ * FFI layer; its boundary for this path is the module-level Python call surface.  Every entry point
+ * below names the reference call it stands in for (file:line relative to the reference tree).  The
+ * Python host side (the modules of score_based_multimodal_autoencoder_amd) binds these with ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only (no torch types).  All device buffers are fp32,
+ * contiguous, 16-byte aligned and owned by the caller.  `stream` is a hipStream_t passed as void*
+ * (NULL = the legacy default stream).  All work is enqueued asynchronously on `stream`; nothing
+ * synchronises except create/destroy, sbm_sampler_run (when timing is requested) and
+ * sbm_model_profile.
+ * Every function returns 0 on success and a non-zero code on failure; sbm_last_error() then
+ * returns a message (thread-local).  No C++ exception crosses this boundary.  A model handle is not
+ * thread-safe; use one handle per device and per batch size.
+ */
+#ifndef SBMAE_H
+#define SBMAE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sbm_model sbm_model;
+
+enum sbm_kind {
+  SBM_UNET = 0,    /* unet_model.Unet (ConvNeXt score net)                 unet_model.py:189-323 */
+  SBM_RESDEC = 1,  /* h_vae_model_copy.ResVAE/ResAE/ResVAEN/ResAEN.decoder  h_vae_model_copy.py:123-126,166-169,489-492,576-579 */
+  SBM_ATTRDEC = 2  /* h_vae_model.CelebAAttrNewBN[AE].decoder               h_vae_model.py:768-769,888-890 */
+};
+
+/* Integer configuration vectors (`cfg`):
+ *   SBM_UNET    [dim, channels, init_dim|0, out_dim|0, with_time_emb, convnext_mult, H, W, n_mults, mults...]
+ *               = the constructor arguments of unet_model.Unet (unet_model.py:190-201) + input size
+ *   SBM_RESDEC  [variant(0 ResVAE/ResAE, 1 ResVAEN/ResAEN), size_in, size_z, img_ch, n_enc, n_dec,
+ *                enc_channel_list (4 ints each)..., dec_channel_list (4 ints each)...]
+ *               = the constructor arguments of ResVAE (h_vae_model_copy.py:92)
+ *   SBM_ATTRDEC [size_z, att_size]   (h_vae_model.py:713)
+ */
+
+const char* sbm_last_error(void);
+int sbm_abi_version(void);
+
+/* state_dict entries a model consumes, in the order `host_tensors` must be passed to
+ * sbm_model_create.  Names are the reference's state_dict keys (torch `load_state_dict` contract,
+ * train_poly_unet_cont.py:563,579).  sbm_spec returns the element count (or -1) and writes the
+ * NUL-terminated key into `name`. */
+int sbm_spec_count(int kind, const int* cfg);
+long sbm_spec(int kind, const int* cfg, int index, char* name, int name_capacity);
+
+/* Build a model for a fixed batch size: packs the weights (host fp32 pointers, reference layouts)
+ * into the device arena and plans the fused kernel sequence.  Replaces module construction +
+ * load_state_dict + .to(device) (train_poly_unet_cont.py:548-580).
+ * `in_pitch`: decoders only -- row pitch in floats of the latent matrix handed to forward (the
+ * reference decodes the strided slice z_out[:, ind].view(B, size_z), train_poly_unet_cont.py:303). */
+int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const float* const* host_tensors,
+                     int n_tensors, sbm_model** out);
+void sbm_model_destroy(sbm_model* m);
+
+/* info[0..7] = n_ops, workspace bytes, parameter bytes, dense FLOP per call, executed FLOP per call,
+ *              n seg_gemm launches, batch, dense FLOP per call computed by seg_gemm launches */
+int sbm_model_info(const sbm_model* m, double* info);
+
+/* One forward pass.
+ *   SBM_UNET:    in = x (B,C,H,W), t = time (B,), out = score (B,C,H,W)        == Unet.forward(x, time), unet_model.py:275
+ *   SBM_RESDEC:  in = z rows (B x size_z, pitch in_pitch), t = NULL, out (B,img_ch,S,S)  == .decoder(z)
+ *   SBM_ATTRDEC: in = z rows, out (B, att_size)                                 == .decoder(z)          */
+int sbm_model_forward(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, void* stream);
+
+/* Per-kernel timing of one forward with HIP events around every launch (eager, `reps` repetitions
+ * after one warm-up).  ms_by_kind[k] / launches_by_kind[k] for k = plan op kind (0 = seg_gemm,
+ * 1 = dwconv7, 2 = linattn, 3 = attn, 4 = gn_res, 5 = sinus, 6 = nchw_to_pbc, 7 = bilinear); sums per forward. */
+int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps,
+                      double* ms_by_kind, int* launches_by_kind, int n_kinds);
+
+/* SDE description == the reference's SDE objects (sde_helper2.py:329-473). kind: 0 VPSDE, 1 subVPSDE, 2 VESDE;
+ * (b0,b1) = (beta_min,beta_max) or (sigma_min,sigma_max). */
+typedef struct sbm_sde_cfg {
+  int kind;
+  double b0, b1;
+  int N;
+  double target_snr;
+  int probability_flow;
+} sbm_sde_cfg;
+
+/* One Euler-Maruyama predictor update given the score  == em_predictor minus its score_fn call
+ * (sde_helper2.py:45-52; PolyMNIST copy train_poly_unet_cont.py:96-102).
+ * noise == NULL: draw N(0,1) in-kernel from Philox keyed by (seed, sample_offset + row, step, draw 0). */
+int sbm_em_step(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t,
+                float* x_out, float* mean_out, int B, int CHW, uint64_t seed, uint64_t sample_offset, int step,
+                void* stream);
+
+/* One Langevin corrector iteration given the score  == the loop body of corrector (sde_helper2.py:96-101).
+ * alphas: device (N,) = 1 - linspace(b0/N, b1/N, N) (ignored for VE); norms_scratch: device 2*B floats. */
+int sbm_langevin_step(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t,
+                      const float* alphas, float* x_out, float* mean_out, float* norms_scratch, int B, int CHW,
+                      uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream);
+
+/* out[b, :] = scale * N(0,1) from the same Philox stream (prior draw: SDE.prior_sampling, sde_helper2.py:364,415,457) */
+int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_t sample_offset, int step, int draw,
+                    float scale, void* stream);
+
+typedef struct sbm_sampler_cfg {
+  int pc;             /* run the Langevin corrector                         (uncond_sampler `pc`) */
+  int n_steps;        /* corrector iterations per step                     (`n_steps`) */
+  int order;          /* 0: corrector -> predictor (sde_helper2.py:121-126); 1: predictor -> corrector (train_poly_unet_cont.py:180-186) */
+  int use_graph;      /* capture one step into a hipGraph and replay it */
+  uint64_t seed;      /* Philox key when noise == NULL */
+  uint64_t sample_offset; /* global index of row 0 (batch sharding) */
+} sbm_sampler_cfg;
+
+/* The whole sampling loop for steps [first_step, first_step + n_run): per step the score net forward
+ * and the predictor / corrector updates  == uncond_sampler's for-loop (sde_helper2.py:120-126).
+ *   timesteps: device (N,) = linspace(T, eps, N);  alphas: device (N,) or NULL when pc == 0
+ *   noise: NULL, or device [(N * draws_per_step)][B][CHW] injected draws in execution order
+ *          (draws_per_step = 1 + pc*n_steps)
+ *   x_inout: state, updated in place;  x_mean_out: the last executed sub-step's mean (what the
+ *   reference returns, sde_helper2.py:128)
+ *   elapsed_ms: NULL, or receives the HIP-event time of the loop on the stream it ran on (synchronises). */
+int sbm_sampler_run(sbm_model* score, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const float* timesteps,
+                    const float* alphas, const float* noise, float* x_inout, float* x_mean_out, int first_step,
+                    int n_run, float* elapsed_ms, void* stream);
+
+/* Debug entry points used only by tests/tools: run the first n_ops ops of the plan (synchronises), read back
+ * workspace floats, name an op ("<kind>:<reference layer>").  Not part of the drop-in surface. */
+int sbm_debug_forward_partial(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int n_ops, void* stream);
+int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int first, int last, void* stream);
+long sbm_debug_workspace_floats(const sbm_model* m);
+int sbm_debug_read_workspace(sbm_model* m, long off, long n, float* host);
+int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SBMAE_H */

@@ -1,0 +1,194 @@
+"""ctypes binding of the C ABI in include/sbmae.h (library csrc/libsbmae_hip.so).
+
+There is deliberately no fallback: if the library is missing or no GPU is visible, every compute
+entry point raises.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libsbmae_hip.so")
+SOURCES = ["plan.cpp", "kernels.hip", "sampler.hip", "api.hip"]
+HEADERS = ["plan.h", "device.h", os.path.join("..", "..", "include", "sbmae.h")]
+
+SBM_UNET, SBM_RESDEC, SBM_ATTRDEC = 0, 1, 2
+OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "nchw_to_pbc", "bilinear"]
+
+EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
+           "sbm_model_info", "sbm_model_forward", "sbm_model_profile", "sbm_em_step", "sbm_langevin_step",
+           "sbm_fill_normal", "sbm_sampler_run", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
+           "sbm_debug_read_workspace", "sbm_debug_op_name"]
+
+
+class SdeCfg(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("b0", ctypes.c_double), ("b1", ctypes.c_double), ("N", ctypes.c_int),
+                ("target_snr", ctypes.c_double), ("probability_flow", ctypes.c_int)]
+
+
+class SamplerCfg(ctypes.Structure):
+    _fields_ = [("pc", ctypes.c_int), ("n_steps", ctypes.c_int), ("order", ctypes.c_int), ("use_graph", ctypes.c_int),
+                ("seed", ctypes.c_uint64), ("sample_offset", ctypes.c_uint64)]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> csrc/libsbmae_hip.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + SOURCES
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load the HIP library (raises if it has not been built -- there is no CPU path)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc, gfx950). This package has no CPU or eager-PyTorch fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ip, i, dbl = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_double
+        u64 = ctypes.c_uint64
+        L.sbm_last_error.restype = ctypes.c_char_p
+        L.sbm_spec_count.argtypes = [i, ip]
+        L.sbm_spec.restype = ctypes.c_long
+        L.sbm_spec.argtypes = [i, ip, i, ctypes.c_char_p, i]
+        L.sbm_model_create.argtypes = [i, ip, i, i, ctypes.POINTER(vp), i, ctypes.POINTER(vp)]
+        L.sbm_model_destroy.argtypes = [vp]
+        L.sbm_model_destroy.restype = None
+        L.sbm_model_info.argtypes = [vp, ctypes.POINTER(dbl)]
+        L.sbm_model_forward.argtypes = [vp, vp, vp, vp, vp]
+        L.sbm_model_profile.argtypes = [vp, vp, vp, vp, i, ctypes.POINTER(dbl), ip, i]
+        L.sbm_em_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, vp]
+        L.sbm_langevin_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
+        L.sbm_fill_normal.argtypes = [vp, ctypes.c_long, i, u64, u64, i, i, ctypes.c_float, vp]
+        L.sbm_sampler_run.argtypes = [vp, ctypes.POINTER(SdeCfg), ctypes.POINTER(SamplerCfg), vp, vp, vp, vp, vp, i, i,
+                                      ctypes.POINTER(ctypes.c_float), vp]
+        L.sbm_debug_forward_partial.argtypes = [vp, vp, vp, vp, i, vp]
+        L.sbm_debug_forward_range.argtypes = [vp, vp, vp, vp, i, i, vp]
+        L.sbm_debug_workspace_floats.restype = ctypes.c_long
+        L.sbm_debug_workspace_floats.argtypes = [vp]
+        L.sbm_debug_read_workspace.argtypes = [vp, ctypes.c_long, ctypes.c_long, vp]
+        L.sbm_debug_op_name.argtypes = [vp, i, ctypes.c_char_p, i]
+        _lib = L
+        return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("sbmae: " + lib().sbm_last_error().decode(errors="replace"))
+
+
+def ints(v):
+    return (ctypes.c_int * len(v))(*[int(x) for x in v])
+
+
+def specs(kind, cfg):
+    """[(state_dict key, numel)] in the order sbm_model_create expects."""
+    L = lib()
+    c = ints(cfg)
+    buf = ctypes.create_string_buffer(256)
+    out = []
+    for k in range(L.sbm_spec_count(kind, c)):
+        n = L.sbm_spec(kind, c, k, buf, 256)
+        out.append((buf.value.decode(), int(n)))
+    return out
+
+
+def unet_cfg_ints(dim, channels, dim_mults, H, W, init_dim=None, out_dim=None, with_time_emb=True, convnext_mult=2):
+    return [dim, channels, init_dim or 0, out_dim or 0, int(bool(with_time_emb)), convnext_mult, H, W, len(dim_mults)] + \
+        [int(m) for m in dim_mults]
+
+
+def resdec_cfg_ints(variant, enc, dec, size_in, size_z, img_ch):
+    v = [variant, size_in, size_z, img_ch, len(enc), len(dec)]
+    for e in enc:
+        v += [int(a) for a in e]
+    for d in dec:
+        v += [int(a) for a in d]
+    return v
+
+
+def _require_cuda(t, what):
+    import torch
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{what} must be a tensor on the GPU: this package runs only on HIP kernels (no CPU path)")
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """A device-resident model for one batch size: packed weights + fused kernel plan."""
+
+    def __init__(self, kind, cfg, batch, state_dict, in_pitch=0):
+        import numpy as np
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: this package has no CPU path")
+        L = lib()
+        self.kind, self.cfg, self.batch = kind, list(cfg), batch
+        sp = specs(kind, cfg)
+        keep = []
+        for name, n in sp:
+            if name not in state_dict:
+                raise KeyError(f"state_dict is missing '{name}'")
+            a = state_dict[name]
+            if isinstance(a, torch.Tensor):
+                a = a.detach().to("cpu", torch.float32).contiguous().numpy()
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.size != n:
+                raise ValueError(f"'{name}' has {a.size} elements, expected {n}")
+            keep.append(a)
+        ptrs = (ctypes.c_void_p * len(sp))(*[a.ctypes.data for a in keep])
+        h = ctypes.c_void_p()
+        check(L.sbm_model_create(kind, ints(cfg), batch, in_pitch, ptrs, len(sp), ctypes.byref(h)))
+        self.h = h
+        info = (ctypes.c_double * 8)()
+        check(L.sbm_model_info(self.h, info))
+        self.info = dict(n_ops=int(info[0]), workspace_bytes=int(info[1]), flops_dense=info[3], flops_exec=info[4], flops_dense_gemm=info[7],
+                         n_gemm=int(info[5]))
+
+    def forward(self, x, t, out):
+        check(lib().sbm_model_forward(self.h, x.data_ptr(), t.data_ptr() if t is not None else None, out.data_ptr(),
+                                      stream_ptr()))
+        return out
+
+    def profile(self, x, t, out, reps=5):
+        n = len(OP_KIND_NAMES)
+        ms = (ctypes.c_double * n)()
+        cnt = (ctypes.c_int * n)()
+        check(lib().sbm_model_profile(self.h, x.data_ptr(), t.data_ptr() if t is not None else None, out.data_ptr(), reps,
+                                      ms, cnt, n))
+        return {OP_KIND_NAMES[k]: dict(ms=ms[k], launches=cnt[k]) for k in range(n)}
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sbm_model_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

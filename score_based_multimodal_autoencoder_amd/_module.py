@@ -1,0 +1,83 @@
+"""Shared host-side plumbing of the drop-in nn.Modules.
+
+Each module owns parameters under exactly the reference's `state_dict` key names (so reference
+checkpoints load with `load_state_dict`), and a cache of device engines (one per batch size) that is
+rebuilt whenever a parameter changes.  The forward never touches the parameters with torch ops: the
+numerics run in the HIP library.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_BUFFER_LEAVES = ("running_mean", "running_var", "num_batches_tracked")
+
+
+class ParamTreeModule(nn.Module):
+    """nn.Module whose sub-module / parameter tree is generated from (dotted name, shape) entries."""
+
+    def _build_tree(self, entries):
+        entries = list(entries)
+        shapes = dict(entries)
+        for name, shape in entries:
+            parts = name.split(".")
+            mod = self
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, nn.Module())
+                mod = mod._modules[p]
+            leaf = parts[-1]
+            if leaf in _BUFFER_LEAVES:
+                if leaf == "num_batches_tracked":
+                    mod.register_buffer(leaf, torch.tensor(0, dtype=torch.long))
+                else:
+                    mod.register_buffer(leaf, torch.zeros(shape) if leaf == "running_mean" else torch.ones(shape))
+                continue
+            t = torch.empty(shape)
+            if len(shape) >= 2:                                  # conv / linear weight: PyTorch's default init
+                fan_in = int(math.prod(shape[1:]))
+                bound = 1.0 / math.sqrt(fan_in)
+                nn.init.uniform_(t, -bound, bound)
+            elif leaf == "bias" and (name[:-4] + "weight") in shapes and len(shapes[name[:-4] + "weight"]) >= 2:
+                fan_in = int(math.prod(shapes[name[:-4] + "weight"][1:]))
+                bound = 1.0 / math.sqrt(fan_in)
+                nn.init.uniform_(t, -bound, bound)
+            elif leaf == "weight":                                # norm scale
+                nn.init.ones_(t)
+            else:                                                 # norm shift
+                nn.init.zeros_(t)
+            mod.register_parameter(leaf, nn.Parameter(t))
+        self._sbm_engines = {}
+        self._sbm_fingerprint = None
+
+    # ---- engine cache ------------------------------------------------------------------------
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def _engine(self, key, factory):
+        fp = self._fingerprint()
+        if fp != self._sbm_fingerprint:
+            for e in self._sbm_engines.values():
+                e.close()
+            self._sbm_engines = {}
+            self._sbm_fingerprint = fp
+        eng = self._sbm_engines.get(key)
+        if eng is None:
+            eng = factory(self.state_dict())
+            self._sbm_engines[key] = eng
+        return eng
+
+    def release_engines(self):
+        for e in self._sbm_engines.values():
+            e.close()
+        self._sbm_engines = {}
+        self._sbm_fingerprint = None
+
+
+def as_f32_cuda(t, what):
+    _lib._require_cuda(t, what)
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()

@@ -1,0 +1,334 @@
+// api.hip -- the C ABI of include/sbmae.h: model handles (plan + device arenas), forward, per-kernel
+// profiling, SDE step entry points and the hipGraph-replayed sampling loop.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sbmae.h"
+#include "device.h"
+#include "plan.h"
+
+using namespace sbm;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+static int fail_hip(const char* what, hipError_t e) { g_err = std::string(what) + ": " + hipGetErrorString(e); return 2; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_hip(#x, e_); } while (0)
+
+struct sbm_model {
+  int kind = 0;
+  Plan plan;
+  float* d_params = nullptr;
+  float* d_ws = nullptr;
+  // sampler scratch (score nets only)
+  float* d_score = nullptr;
+  float* d_norms = nullptr;
+  int* d_counter = nullptr;
+  hipStream_t own = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+};
+
+static UnetCfg unet_cfg_from_ints(const int* c) {
+  UnetCfg u; u.dim = c[0]; u.channels = c[1]; u.init_dim = c[2]; u.out_dim = c[3]; u.with_time_emb = c[4]; u.convnext_mult = c[5];
+  u.H = c[6]; u.W = c[7]; u.n_mults = c[8] < 8 ? c[8] : 8;
+  for (int i = 0; i < u.n_mults; ++i) u.dim_mults[i] = c[9 + i];
+  return u;
+}
+static ResDecCfg resdec_cfg_from_ints(const int* c) {
+  ResDecCfg r; r.variant = c[0]; r.size_in = c[1]; r.size_z = c[2]; r.img_ch = c[3]; r.n_enc = c[4] < 8 ? c[4] : 8; r.n_dec = c[5] < 8 ? c[5] : 8;
+  const int* e = c + 6;
+  for (int i = 0; i < r.n_enc; ++i) for (int j = 0; j < 4; ++j) r.enc[i][j] = *e++;
+  for (int i = 0; i < r.n_dec; ++i) for (int j = 0; j < 4; ++j) r.dec[i][j] = *e++;
+  return r;
+}
+static std::vector<TensorSpec> specs_of(int kind, const int* cfg) {
+  if (kind == SBM_UNET) return unet_tensor_specs(unet_cfg_from_ints(cfg));
+  if (kind == SBM_RESDEC) return resdec_tensor_specs(resdec_cfg_from_ints(cfg));
+  if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; return attrdec_tensor_specs(a); }
+  return {};
+}
+
+static SdeParams make_sde(const sbm_sde_cfg& c) {
+  SdeParams s{};
+  s.kind = c.kind; s.b0 = (float)c.b0; s.b1 = (float)c.b1; s.b1_minus_b0 = (float)(c.b1 - c.b0);
+  s.ve_ratio = (float)(c.b1 / c.b0);
+  s.ve_gconst = c.kind == 2 ? (float)std::sqrt(2.0 * (std::log(c.b1) - std::log(c.b0))) : 0.f;
+  s.dt = (float)(-1.0 / c.N); s.sqrt_mdt = (float)std::sqrt(1.0 / c.N);
+  s.snr = (float)c.target_snr; s.N = c.N; s.probability_flow = c.probability_flow;
+  return s;
+}
+
+extern "C" {
+
+const char* sbm_last_error(void) { return g_err.c_str(); }
+int sbm_abi_version(void) { return 1; }
+
+int sbm_spec_count(int kind, const int* cfg) { return (int)specs_of(kind, cfg).size(); }
+
+long sbm_spec(int kind, const int* cfg, int index, char* name, int cap) {
+  std::vector<TensorSpec> s = specs_of(kind, cfg);
+  if (index < 0 || index >= (int)s.size() || cap <= 0) return -1;
+  std::strncpy(name, s[index].name.c_str(), cap - 1); name[cap - 1] = 0;
+  return (long)s[index].numel();
+}
+
+void sbm_model_destroy(sbm_model* m) {
+  if (!m) return;
+  if (m->own) (void)hipStreamSynchronize(m->own);
+  if (m->d_params) (void)hipFree(m->d_params);
+  if (m->d_ws) (void)hipFree(m->d_ws);
+  if (m->d_score) (void)hipFree(m->d_score);
+  if (m->d_norms) (void)hipFree(m->d_norms);
+  if (m->d_counter) (void)hipFree(m->d_counter);
+  if (m->ev_in) (void)hipEventDestroy(m->ev_in);
+  if (m->ev_out) (void)hipEventDestroy(m->ev_out);
+  if (m->ev_t0) (void)hipEventDestroy(m->ev_t0);
+  if (m->ev_t1) (void)hipEventDestroy(m->ev_t1);
+  if (m->own) (void)hipStreamDestroy(m->own);
+  delete m;
+}
+
+int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const float* const* host_tensors, int n_tensors, sbm_model** out) {
+  if (!cfg || !host_tensors || !out || batch <= 0) return fail("sbm_model_create: bad arguments");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("sbm_model_create: no HIP device (this library has no CPU path)");
+  if ((int)specs_of(kind, cfg).size() != n_tensors) return fail("sbm_model_create: tensor count does not match sbm_spec_count");
+  sbm_model* m = new (std::nothrow) sbm_model();
+  if (!m) return fail("out of host memory");
+  m->kind = kind;
+  bool ok = false;
+  if (kind == SBM_UNET) ok = build_unet_plan(unet_cfg_from_ints(cfg), batch, host_tensors, &m->plan);
+  else if (kind == SBM_RESDEC) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), batch, in_pitch, host_tensors, &m->plan);
+  else if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, batch, in_pitch, host_tensors, &m->plan); }
+  else m->plan.error = "unknown model kind";
+  if (!ok) { std::string e = m->plan.error; delete m; return fail("sbm_model_create: " + e); }
+  const size_t pbytes = m->plan.params.size() * sizeof(float), wbytes = (size_t)m->plan.ws_floats * sizeof(float);
+  hipError_t e;
+  if ((e = hipMalloc(&m->d_params, pbytes ? pbytes : 16)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(params)", e); }
+  if ((e = hipMalloc(&m->d_ws, wbytes ? wbytes : 16)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(workspace)", e); }
+  if ((e = hipMemcpy(m->d_params, m->plan.params.data(), pbytes, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(params)", e); }
+  if ((e = hipMemset(m->d_ws, 0, wbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemset(workspace)", e); }
+  std::vector<float>().swap(m->plan.params);          // host copy no longer needed
+  if (kind == SBM_UNET) {
+    const size_t sbytes = (size_t)batch * m->plan.out_C * m->plan.out_H * m->plan.out_W * sizeof(float);
+    if ((e = hipMalloc(&m->d_score, sbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(score)", e); }
+    if ((e = hipMalloc(&m->d_norms, (size_t)batch * 2 * sizeof(float))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(norms)", e); }
+    if ((e = hipMalloc(&m->d_counter, 64)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(counter)", e); }
+    (void)hipMemset(m->d_counter, 0, 64);
+  }
+  if ((e = hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipStreamCreate", e); }
+  (void)hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming); (void)hipEventCreateWithFlags(&m->ev_out, hipEventDisableTiming);
+  (void)hipEventCreate(&m->ev_t0); (void)hipEventCreate(&m->ev_t1);
+  if ((e = hipDeviceSynchronize()) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipDeviceSynchronize", e); }
+  *out = m;
+  return 0;
+}
+
+int sbm_model_info(const sbm_model* m, double* info) {
+  if (!m || !info) return fail("sbm_model_info: bad arguments");
+  int ng = 0; for (auto& op : m->plan.ops) ng += op.kind == OP_GEMM;
+  info[0] = (double)m->plan.ops.size(); info[1] = (double)m->plan.ws_floats * 4; info[2] = 0;
+  info[3] = m->plan.flops_dense; info[4] = m->plan.flops_exec; info[5] = ng; info[6] = m->plan.B; info[7] = m->plan.flops_dense_gemm;
+  return 0;
+}
+
+int sbm_model_forward(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, void* stream) {
+  if (!m || !in_dev || !out_dev) return fail("sbm_model_forward: bad arguments");
+  if (m->plan.needs_time && !t_dev) return fail("sbm_model_forward: this score net needs a time vector");
+  const char* e = run_plan(m->plan, m->d_params, m->d_ws, in_dev, t_dev, out_dev, (hipStream_t)stream);
+  return e ? fail(std::string("sbm_model_forward: ") + e) : 0;
+}
+
+// ---- debug entry points (tests/tools only): run the first n_ops ops, read back the workspace ----
+int sbm_debug_forward_partial(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int n_ops, void* stream) {
+  if (!m || !in_dev || !out_dev) return fail("sbm_debug_forward_partial: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
+  for (int i = 0; i < n_ops && i < (int)m->plan.ops.size(); ++i) {
+    const char* e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, st);
+    if (e) return fail(e);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int first, int last, void* stream) {
+  if (!m || !in_dev || !out_dev) return fail("sbm_debug_forward_range: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  if (first == 0 && m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
+  for (int i = first; i < last && i < (int)m->plan.ops.size(); ++i) {
+    const char* e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, st);
+    if (e) return fail(e);
+  }
+  HIPCHK(hipStreamSynchronize(st));
+  return 0;
+}
+long sbm_debug_workspace_floats(const sbm_model* m) { return m ? (long)m->plan.ws_floats : -1; }
+int sbm_debug_read_workspace(sbm_model* m, long off, long n, float* host) {
+  if (!m || !host || off < 0 || off + n > (long)m->plan.ws_floats) return fail("sbm_debug_read_workspace: bad range");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(host, m->d_ws + off, sizeof(float) * n, hipMemcpyDeviceToHost));
+  return 0;
+}
+int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap) {
+  if (!m || i < 0 || i >= (int)m->plan.ops.size() || cap <= 0) return fail("sbm_debug_op_name: bad index");
+  std::string s = std::to_string(m->plan.ops[i].kind) + ":" + m->plan.ops[i].name;
+  std::strncpy(name, s.c_str(), cap - 1); name[cap - 1] = 0;
+  return 0;
+}
+
+int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, double* ms_by_kind, int* launches_by_kind, int n_kinds) {
+  if (!m || !in_dev || !out_dev || reps <= 0 || !ms_by_kind || !launches_by_kind) return fail("sbm_model_profile: bad arguments");
+  for (int k = 0; k < n_kinds; ++k) { ms_by_kind[k] = 0; launches_by_kind[k] = 0; }
+  hipStream_t st = m->own;
+  const char* e = run_plan(m->plan, m->d_params, m->d_ws, in_dev, t_dev, out_dev, st);       // warm-up
+  if (e) return fail(e);
+  HIPCHK(hipStreamSynchronize(st));
+  const size_t nops = m->plan.ops.size();
+  std::vector<hipEvent_t> ev(nops + 1);
+  for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+  for (int r = 0; r < reps; ++r) {
+    if (m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipEventRecord(ev[0], st));
+    for (size_t i = 0; i < nops; ++i) {
+      e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, st);
+      if (e) return fail(e);
+      HIPCHK(hipEventRecord(ev[i + 1], st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < nops; ++i) {
+      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      const int k = m->plan.ops[i].kind;
+      if (k < n_kinds) { ms_by_kind[k] += ms / reps; if (r == 0) launches_by_kind[k] += 1; }
+    }
+  }
+  for (auto& x : ev) (void)hipEventDestroy(x);
+  return 0;
+}
+
+static StepArgs step_args(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t, float* x_out, float* mean_out,
+                          int B, int CHW, uint64_t seed, uint64_t sample_offset, int step, int draw) {
+  StepArgs a{};
+  a.x = x; a.score = score; a.noise = noise; a.t = t; a.x_out = x_out; a.mean_out = mean_out; a.B = B; a.CHW = CHW;
+  a.seed = seed; a.sample_offset = sample_offset; a.step_base = step; a.draw = draw; a.sde = make_sde(*sde);
+  return a;
+}
+
+int sbm_em_step(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t, float* x_out, float* mean_out,
+                int B, int CHW, uint64_t seed, uint64_t sample_offset, int step, void* stream) {
+  if (!sde || !x || !score || !t || !x_out || !mean_out || B <= 0 || CHW <= 0) return fail("sbm_em_step: bad arguments");
+  if (CHW % 4) return fail("sbm_em_step: C*H*W must be a multiple of 4");
+  StepArgs a = step_args(sde, x, score, noise, t, x_out, mean_out, B, CHW, seed, sample_offset, step, 0);
+  launch_em_step(a, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sbm_langevin_step(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t, const float* alphas,
+                      float* x_out, float* mean_out, float* norms_scratch, int B, int CHW, uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream) {
+  if (!sde || !x || !score || !t || !x_out || !mean_out || !norms_scratch || B <= 0 || CHW <= 0) return fail("sbm_langevin_step: bad arguments");
+  if (sde->kind != 2 && !alphas) return fail("sbm_langevin_step: VP/subVP need the alphas table");
+  if (CHW % 4) return fail("sbm_langevin_step: C*H*W must be a multiple of 4");
+  StepArgs a = step_args(sde, x, score, noise, t, x_out, mean_out, B, CHW, seed, sample_offset, step, draw);
+  a.alphas = alphas; a.norms = norms_scratch;
+  launch_langevin_step(a, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_t sample_offset, int step, int draw, float scale, void* stream) {
+  if (!out || n_per_sample <= 0 || n_per_sample % 4 || B <= 0) return fail("sbm_fill_normal: bad arguments (n_per_sample must be a positive multiple of 4)");
+  launch_fill_normal(out, n_per_sample, B, seed, sample_offset, (unsigned)step, (unsigned)draw, scale, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// one full sampling step enqueued on `st` (graph-capturable: no allocation, no sync, step index read on device)
+static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sampler_cfg& c, const float* timesteps, const float* alphas, const float* noise,
+                                float* x, float* x_mean, hipStream_t st) {
+  const Plan& P = m->plan;
+  const int B = P.B, CHW = P.out_C * P.out_H * P.out_W;
+  const int dps = 1 + (c.pc ? c.n_steps : 0);
+  float* tbuf = m->d_ws + P.time_off;
+  StepArgs a{};
+  a.x = x; a.score = m->d_score; a.noise = noise; a.t = nullptr; a.timesteps = timesteps; a.step_counter = m->d_counter; a.alphas = alphas;
+  a.x_out = x; a.mean_out = x_mean; a.norms = m->d_norms; a.seed = c.seed; a.sample_offset = c.sample_offset; a.B = B; a.CHW = CHW; a.sde = sp;
+  a.noise_step_stride = (long long)dps * B * CHW;
+  auto score_eval = [&]() -> const char* {
+    launch_fill_time(tbuf, timesteps, m->d_counter, B, st);
+    return run_plan(P, m->d_params, m->d_ws, x, tbuf, m->d_score, st);
+  };
+  auto corrector = [&](int first_draw) -> const char* {
+    for (int i = 0; i < c.n_steps; ++i) {
+      const char* e = score_eval(); if (e) return e;
+      a.draw = first_draw + i; a.noise_draw_off = (long long)(first_draw + i) * B * CHW;
+      launch_langevin_step(a, st);
+    }
+    return nullptr;
+  };
+  auto predictor = [&](int draw) -> const char* {
+    const char* e = score_eval(); if (e) return e;
+    a.draw = draw; a.noise_draw_off = (long long)draw * B * CHW;
+    launch_em_step(a, st);
+    return nullptr;
+  };
+  const char* e = nullptr;
+  if (c.order == 0) {                      // sde_helper2.uncond_sampler: corrector, then predictor
+    if (c.pc && (e = corrector(0))) return e;
+    if ((e = predictor(c.pc ? c.n_steps : 0))) return e;
+  } else {                                 // train_poly_unet_cont.uncond_sampler: predictor, then corrector
+    if ((e = predictor(0))) return e;
+    if (c.pc && (e = corrector(1))) return e;
+  }
+  launch_advance(m->d_counter, st);
+  return nullptr;
+}
+
+int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const float* timesteps, const float* alphas, const float* noise,
+                    float* x_inout, float* x_mean_out, int first_step, int n_run, float* elapsed_ms, void* stream) {
+  if (!m || m->kind != SBM_UNET || !sde || !cfg || !timesteps || !x_inout || !x_mean_out) return fail("sbm_sampler_run: bad arguments");
+  if (!m->plan.needs_time) return fail("sbm_sampler_run: the score net has no time embedding");
+  if (first_step < 0 || n_run < 0 || first_step + n_run > sde->N) return fail("sbm_sampler_run: step range outside [0, N)");
+  if (cfg->pc && cfg->n_steps <= 0) return fail("sbm_sampler_run: n_steps must be positive when pc is set");
+  if (cfg->pc && sde->kind != 2 && !alphas) return fail("sbm_sampler_run: VP/subVP corrector needs the alphas table");
+  const int CHW = m->plan.out_C * m->plan.out_H * m->plan.out_W;
+  if (CHW % 4) return fail("sbm_sampler_run: C*H*W must be a multiple of 4");
+  if (m->plan.in_C != m->plan.out_C) return fail("sbm_sampler_run: score net must map the state onto itself");
+  const SdeParams sp = make_sde(*sde);
+  hipStream_t caller = (hipStream_t)stream, st = m->own;
+  HIPCHK(hipEventRecord(m->ev_in, caller));
+  HIPCHK(hipStreamWaitEvent(st, m->ev_in, 0));
+  launch_set_counter(m->d_counter, first_step, st);
+  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  const char* e = nullptr;
+  if (cfg->use_graph && n_run > 1) {
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st);
+    hipError_t ce = hipStreamEndCapture(st, &graph);
+    if (e) { if (graph) (void)hipGraphDestroy(graph); return fail(std::string("sbm_sampler_run: ") + e); }
+    if (ce != hipSuccess) return fail_hip("hipStreamEndCapture", ce);
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  }
+  if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t0, st));
+  for (int i = 0; i < n_run; ++i) {
+    if (exec) { hipError_t le = hipGraphLaunch(exec, st); if (le != hipSuccess) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); return fail_hip("hipGraphLaunch", le); } }
+    else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st))) return fail(std::string("sbm_sampler_run: ") + e);
+  }
+  if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t1, st));
+  HIPCHK(hipEventRecord(m->ev_out, st));
+  HIPCHK(hipStreamWaitEvent(caller, m->ev_out, 0));
+  if (elapsed_ms || exec) {
+    hipError_t se = hipStreamSynchronize(st);
+    if (exec) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); }
+    if (se != hipSuccess) return fail_hip("hipStreamSynchronize", se);
+    if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, m->ev_t0, m->ev_t1));
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+}  // extern "C"

@@ -6,6 +6,7 @@
 // checked against the oracle on a machine without a GPU, and so that each HIP kernel can be tested
 // against the descriptor semantics op by op.  It is not a fallback: nothing in the product path
 // references it.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <string>
@@ -196,10 +197,12 @@ static void run_bilinear(const BilinearOp& o, float* ws) {
   }
 }
 
-void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const float* t, float* out) {
+void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const float* t, float* out, int n_ops = 1 << 30) {
   const float* prm = plan.params.data();
   if (plan.time_off >= 0 && t) std::memcpy(&ws[plan.time_off], t, sizeof(float) * plan.B);
+  int done = 0;
   for (const Op& op : plan.ops) {
+    if (done++ >= n_ops) break;
     switch (op.kind) {
       case OP_GEMM: run_gemm(op.g, prm, ws.data(), in, out); break;
       case OP_DWCONV7: run_dw(op.dw, prm, ws.data()); break;
@@ -301,6 +304,29 @@ void sbmref_info(void* hv, double* o) {
   o[0] = (double)h->plan.ops.size(); o[1] = (double)h->plan.ws_floats; o[2] = (double)h->plan.params.size();
   o[3] = h->plan.flops_dense; o[4] = h->plan.flops_exec; o[5] = ng;
 }
+
+int sbmref_run_partial(void* hv, const float* in, const float* t, float* out, int n_ops) {
+  RefHandle* h = (RefHandle*)hv;
+  interpret(h->plan, h->ws, in, t, out, n_ops);
+  return 0;
+}
+int sbmref_run_range(void* hv, const float* in, const float* t, float* out, int first, int last) {
+  RefHandle* h = (RefHandle*)hv;
+  Plan sub = h->plan;                      // copy of descriptors only (params vector copied too; test-only)
+  if (first > 0) sub.time_off = h->plan.time_off;
+  std::vector<Op> ops(h->plan.ops.begin() + first, h->plan.ops.begin() + std::min<size_t>(last, h->plan.ops.size()));
+  sub.ops.swap(ops);
+  interpret(sub, h->ws, in, first == 0 ? t : nullptr, out);
+  return 0;
+}
+int sbmref_op_name(void* hv, int i, char* name, int cap) {
+  RefHandle* h = (RefHandle*)hv;
+  if (i < 0 || i >= (int)h->plan.ops.size()) return 1;
+  std::string s = std::to_string(h->plan.ops[i].kind) + ":" + h->plan.ops[i].name;
+  std::strncpy(name, s.c_str(), cap - 1); name[cap - 1] = 0;
+  return 0;
+}
+const float* sbmref_workspace(void* hv) { return ((RefHandle*)hv)->ws.data(); }
 
 void sbmref_free(void* hv) { delete (RefHandle*)hv; }
 

@@ -350,6 +350,7 @@ class Builder {
       }
     double dense_taps = s.transposed ? (double)s.a.H * s.a.W * s.kh * s.kw : (double)P * s.kh * s.kw;
     plan->flops_dense += 2.0 * B * s.cout * (dense_taps * s.cin_true + (s.has2 ? (double)P * s.cin2 : 0.0));
+    plan->flops_dense_gemm += 2.0 * B * s.cout * (dense_taps * s.cin_true + (s.has2 ? (double)P * s.cin2 : 0.0));
     plan->flops_exec += 2.0 * B * g.Npad * (taps_valid * s.a.C + (s.has2 ? (double)P * s.a2.C : 0.0));
     return res;
   }
@@ -529,7 +530,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
         std::memcpy(&cond_w[(size_t)(col + cm.idx[c]) * d.td], &w[(size_t)c * d.td], sizeof(float) * d.td);
         cond_b[col + cm.idx[c]] = bb[c];
       }
-      plan->flops_dense += 2.0 * B * cin * d.td;
+      plan->flops_dense += 2.0 * B * cin * d.td; plan->flops_dense_gemm += 2.0 * B * cin * d.td;
     };
 
     // init conv 7x7
@@ -703,7 +704,7 @@ bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const
       g.bias_off = b.add_params(bp); g.bias_pix_stride = g.Npad;
       g.act = ACT_RELU; g.out = h;
       Builder::choose_tile(B, P0, pad8(clast), &g.BM, &g.BN);
-      plan->flops_dense += 2.0 * B * P0 * clast * cfg.size_z;
+      plan->flops_dense += 2.0 * B * P0 * clast * cfg.size_z; plan->flops_dense_gemm += 2.0 * B * P0 * clast * cfg.size_z;
       plan->flops_exec += 2.0 * B * P0 * g.Npad * cfg.size_z;
     }
     const int act = cfg.variant == 0 ? ACT_LRELU02 : ACT_GELU;

@@ -12,6 +12,12 @@
 #include <string>
 #include <vector>
 
+#if defined(__HIPCC__)
+#define SBM_HD __host__ __device__
+#else
+#define SBM_HD
+#endif
+
 namespace sbm {
 
 enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU02 = 2, ACT_RELU = 3, ACT_SIGMOID = 4, ACT_SILU = 5 };
@@ -129,6 +135,7 @@ struct Plan {
   int64_t time_off = -1;         // workspace [B] : the plan's time input is copied here
   double flops_dense = 0;        // 2*MAC, dense convention (zero-padding taps counted)
   double flops_exec = 0;         // 2*MAC actually issued (padding taps skipped, channel padding included)
+  double flops_dense_gemm = 0;   // the part of flops_dense computed by seg_gemm launches
   std::string error;
 };
 
@@ -162,12 +169,12 @@ struct AttrDecCfg { int size_z = 256, att_size = 18; };
 std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& cfg);
 bool build_attrdec_plan(const AttrDecCfg& cfg, int B, int z_ld, const float* const* tensors, Plan* plan);
 
-inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+SBM_HD inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
 // Source pixel (in the stored, pre-upsample grid of source 1) that tap (ky,kx) of output pixel (oy,ox)
 // reads, or -1 when the tap falls into the zero padding (then it is skipped).
-inline int tap_source_pixel(int oy, int ox, int ky, int kx, int stride, int pad, int transposed, int up, int Hs, int Ws) {
+SBM_HD inline int tap_source_pixel(int oy, int ox, int ky, int kx, int stride, int pad, int transposed, int up, int Hs, int Ws) {
   int iy, ix;
   const int He = Hs * up, We = Ws * up;
   if (!transposed) {

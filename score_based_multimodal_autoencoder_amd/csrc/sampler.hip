@@ -1,0 +1,176 @@
+// sampler.hip -- elementwise kernels of the reverse-SDE sampling loop (HBM-bound, 16-byte coalesced).
+//
+//   em_step        em_predictor + RSDE.sde   (reference sde_helper2.py:45-52, 277-317, 352-356, 402-407, 445-450)
+//   langevin_step  one corrector iteration   (reference sde_helper2.py:96-101)
+//   philox normal  counter-based N(0,1) keyed by (seed, GLOBAL sample index, step, draw): the stream a
+//                  sample sees does not depend on how the batch is sharded over GPUs.
+// The arithmetic follows the reference's operator order with FMA contraction disabled, so that the
+// update agrees with PyTorch's unfused fp32 ops to the last bit wherever libm is not involved.
+#include <hip/hip_runtime.h>
+
+#include "device.h"
+
+namespace sbm {
+
+#pragma clang fp contract(off)
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// four N(0,1) for elements [4*e4, 4*e4+4) of global sample `gs` at (step, draw)
+__device__ __forceinline__ float4 normal4(unsigned long long seed, unsigned long long gs, unsigned e4, unsigned step, unsigned draw) {
+  unsigned r[4];
+  philox4x32_10(e4, (unsigned)gs, (unsigned)(gs >> 32) ^ (draw << 24), step, (unsigned)seed, (unsigned)(seed >> 32), r);
+  const float u0 = ((r[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = (r[1] >> 8) * (1.0f / 16777216.0f);
+  const float u2 = ((r[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = (r[3] >> 8) * (1.0f / 16777216.0f);
+  const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+  float sa, ca, sb, cb;
+  sincospif(2.0f * u1, &sa, &ca); sincospif(2.0f * u3, &sb, &cb);
+  return make_float4(ra * ca, ra * sa, rb * cb, rb * sb);
+}
+
+__device__ __forceinline__ float4 load_noise4(const StepArgs& a, int b, int e, unsigned step) {
+  if (a.noise) return *reinterpret_cast<const float4*>(a.noise + (long long)step * a.noise_step_stride + a.noise_draw_off + (long long)b * a.CHW + e);
+  return normal4(a.seed, a.sample_offset + (unsigned long long)b, (unsigned)(e >> 2), step, (unsigned)a.draw);
+}
+
+// ---- SDE coefficients (per sample) ---------------------------------------------------------------
+struct Coef { float dcoef, g; };
+__device__ __forceinline__ Coef sde_coef(const SdeParams& s, float t) {
+  Coef c;
+  if (s.kind == 2) {                        // VESDE.sde sde_helper2.py:445-450
+    const float sigma = s.b0 * powf(s.ve_ratio, t);
+    c.dcoef = 0.f; c.g = sigma * s.ve_gconst;
+    return c;
+  }
+  const float beta_t = s.b0 + t * s.b1_minus_b0;       // VPSDE.sde sde_helper2.py:352-356
+  c.dcoef = -0.5f * beta_t;
+  if (s.kind == 0) c.g = sqrtf(beta_t);
+  else {                                               // subVPSDE.sde sde_helper2.py:402-407
+    const float e = expf((-2.0f * s.b0) * t - s.b1_minus_b0 * (t * t));
+    c.g = sqrtf(beta_t * (1.0f - e));
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(256) void em_step_kernel(const StepArgs a) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 per thread
+  const int q4 = a.CHW >> 2;
+  if (idx >= (long long)a.B * q4) return;
+  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
+  const int stepi = a.step_counter ? *a.step_counter : a.step_base;
+  const float t = a.t ? a.t[b] : a.timesteps[stepi];
+  const Coef c = sde_coef(a.sde, t);
+  const float4 x = *reinterpret_cast<const float4*>(a.x + (long long)b * a.CHW + e);
+  const float4 s = *reinterpret_cast<const float4*>(a.score + (long long)b * a.CHW + e);
+  const float g2 = c.g * c.g;
+  const float pf = a.sde.probability_flow ? 0.5f : 1.0f;
+  const float gz = a.sde.probability_flow ? 0.0f : c.g * a.sde.sqrt_mdt;
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!a.sde.probability_flow) z = load_noise4(a, b, e, (unsigned)stepi);
+  float4 m, o;
+#define SBM_EM(C) { const float drift = (c.dcoef * x.C) - (g2 * s.C) * pf; m.C = x.C + drift * a.sde.dt; o.C = m.C + gz * z.C; }
+  SBM_EM(x) SBM_EM(y) SBM_EM(z) SBM_EM(w)
+#undef SBM_EM
+  *reinterpret_cast<float4*>(a.mean_out + (long long)b * a.CHW + e) = m;
+  *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
+}
+
+// per-sample L2 norms of the score and of the corrector's noise: one workgroup per sample
+__global__ __launch_bounds__(256) void norms_kernel(const StepArgs a) {
+  __shared__ float rs[256], rn[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int stepi = a.step_counter ? *a.step_counter : a.step_base;
+  float s = 0.f, n = 0.f;
+  for (int e = tid * 4; e < a.CHW; e += 1024) {
+    const float4 g = *reinterpret_cast<const float4*>(a.score + (long long)b * a.CHW + e);
+    const float4 z = load_noise4(a, b, e, (unsigned)stepi);
+    s += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+    n += z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w;
+  }
+  rs[tid] = s; rn[tid] = n;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) { if (tid < o) { rs[tid] += rs[tid + o]; rn[tid] += rn[tid + o]; } __syncthreads(); }
+  if (tid == 0) { a.norms[2 * b] = sqrtf(rs[0]); a.norms[2 * b + 1] = sqrtf(rn[0]); }
+}
+
+__global__ __launch_bounds__(256) void langevin_update_kernel(const StepArgs a) {
+  __shared__ float rs[256], rn[256];
+  const int tid = threadIdx.x;
+  // batch-mean norms (sde_helper2.py:97-98): every workgroup reduces the B per-sample norms itself
+  float s = 0.f, n = 0.f;
+  for (int i = tid; i < a.B; i += 256) { s += a.norms[2 * i]; n += a.norms[2 * i + 1]; }
+  rs[tid] = s; rn[tid] = n;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) { if (tid < o) { rs[tid] += rs[tid + o]; rn[tid] += rn[tid + o]; } __syncthreads(); }
+  const float gnorm = rs[0] / (float)a.B, nnorm = rn[0] / (float)a.B;
+  const long long idx = (long long)blockIdx.x * blockDim.x + tid;
+  const int q4 = a.CHW >> 2;
+  if (idx >= (long long)a.B * q4) return;
+  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
+  const int stepi = a.step_counter ? *a.step_counter : a.step_base;
+  const float t = a.t ? a.t[b] : a.timesteps[stepi];
+  float alpha = 1.0f;
+  if (a.sde.kind != 2) {                                            // sde_helper2.py:56-60
+    int ai = (int)((t * (float)(a.sde.N - 1)) / 1.0f);
+    ai = ai < 0 ? 0 : (ai > a.sde.N - 1 ? a.sde.N - 1 : ai);
+    alpha = a.alphas[ai];
+  }
+  const float r = (a.sde.snr * nnorm) / gnorm;
+  const float step = ((r * r) * 2.0f) * alpha;                      // sde_helper2.py:99
+  const float sq = sqrtf(step * 2.0f);
+  const float4 x = *reinterpret_cast<const float4*>(a.x + (long long)b * a.CHW + e);
+  const float4 g = *reinterpret_cast<const float4*>(a.score + (long long)b * a.CHW + e);
+  const float4 z = load_noise4(a, b, e, (unsigned)stepi);
+  float4 m, o;
+  m.x = x.x + step * g.x; m.y = x.y + step * g.y; m.z = x.z + step * g.z; m.w = x.w + step * g.w;
+  o.x = m.x + sq * z.x; o.y = m.y + sq * z.y; o.z = m.z + sq * z.z; o.w = m.w + sq * z.w;
+  *reinterpret_cast<float4*>(a.mean_out + (long long)b * a.CHW + e) = m;
+  *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
+}
+
+__global__ void fill_time_kernel(float* t_out, const float* timesteps, const int* step_counter, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) t_out[i] = timesteps[*step_counter];
+}
+__global__ void advance_kernel(int* step_counter) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_counter += 1; }
+
+__global__ void fill_normal_kernel(float* out, long long q4, int B, unsigned long long seed, unsigned long long sample_offset, unsigned step, unsigned draw, float scale) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * q4) return;
+  const int b = (int)(idx / q4); const long long e4 = idx - (long long)b * q4;
+  float4 z = normal4(seed, sample_offset + (unsigned long long)b, (unsigned)e4, step, draw);
+  z.x *= scale; z.y *= scale; z.z *= scale; z.w *= scale;
+  *reinterpret_cast<float4*>(out + ((long long)b * q4 + e4) * 4) = z;
+}
+
+void launch_em_step(const StepArgs& a, hipStream_t st) {
+  const long long n = (long long)a.B * (a.CHW >> 2);
+  hipLaunchKernelGGL(em_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_langevin_step(const StepArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(norms_kernel, dim3(a.B), dim3(256), 0, st, a);
+  const long long n = (long long)a.B * (a.CHW >> 2);
+  hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+}
+void launch_fill_time(float* t_out, const float* timesteps, const int* step_counter, int B, hipStream_t st) {
+  hipLaunchKernelGGL(fill_time_kernel, dim3((B + 255) / 256), dim3(256), 0, st, t_out, timesteps, step_counter, B);
+}
+__global__ void set_counter_kernel(int* step_counter, int v) { if (threadIdx.x == 0 && blockIdx.x == 0) *step_counter = v; }
+void launch_set_counter(int* step_counter, int value, hipStream_t st) { hipLaunchKernelGGL(set_counter_kernel, dim3(1), dim3(64), 0, st, step_counter, value); }
+void launch_advance(int* step_counter, hipStream_t st) { hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, step_counter); }
+void launch_fill_normal(float* out, long long n_per_sample, int B, unsigned long long seed, unsigned long long sample_offset, unsigned step, unsigned draw, float scale, hipStream_t st) {
+  const long long q4 = n_per_sample >> 2, n = (long long)B * q4;
+  hipLaunchKernelGGL(fill_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, out, q4, B, seed, sample_offset, step, draw, scale);
+}
+
+}  // namespace sbm

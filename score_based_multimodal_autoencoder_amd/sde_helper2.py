@@ -1,0 +1,294 @@
+"""Drop-in for the sampling half of the reference's `sde_helper2.py`:
+
+    VPSDE / subVPSDE / VESDE          (sde_helper2.py:329-473)
+    em_predictor, corrector           (sde_helper2.py:45-106)
+    uncond_sampler                    (sde_helper2.py:115-128)
+
+The z-updates (Euler-Maruyama predictor, Langevin corrector, their batch-mean norms) and -- when the
+score model is this package's `Unet` -- the whole N-step loop run in the HIP library; the loop is
+captured once into a hipGraph and replayed.  Training-only helpers (loss_fn, JAX importance
+sampling) and classifier guidance are out of scope: passing `cl_g` raises.
+
+Additions, all keyword-only and defaulted so reference call sites keep working:
+    order  'cp' (corrector then predictor, sde_helper2.uncond_sampler) or
+           'pc' (predictor then corrector, train_poly_unet_cont.uncond_sampler)
+    noise  injected draws (parity tests): tensor [(N * draws_per_step), B, C, H, W] in execution order
+    x0     initial state instead of sde.prior_sampling(shape)
+    seed / sample_offset   Philox key and global index of row 0 (results do not depend on sharding)
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._module import as_f32_cuda
+
+
+class SDE:
+    """Common surface of the reference's SDE ABC (sde_helper2.py:191-326)."""
+    kind = -1
+
+    def __init__(self, N):
+        self.N = N
+
+    @property
+    def T(self):
+        return 1
+
+    def _cfg(self, target_snr=0.16, probability_flow=False):
+        return _lib.SdeCfg(self.kind, float(self.beta_0), float(self.beta_1), int(self.N), float(target_snr),
+                           int(bool(probability_flow)))
+
+    def prior_sampling(self, shape):
+        return torch.randn(*shape)                       # host RNG, as the reference (sde_helper2.py:364)
+
+    def prior_logp(self, z):
+        n = np.prod(z.shape[1:])
+        return -n / 2. * np.log(2 * np.pi) - torch.sum(z ** 2, dim=(1, 2, 3)) / 2.
+
+    def discretize(self, x, t):
+        dt = 1 / self.N
+        drift, diffusion = self.sde(x, t)
+        return drift * dt, diffusion * math.sqrt(dt)
+
+    def reverse(self, score_fn, probability_flow=False):
+        """Reverse-time SDE/ODE object with the reference RSDE's `.sde` / `.discretize` (sde_helper2.py:255-326)."""
+        return _Reverse(self, score_fn, probability_flow)
+
+    # light-weight tensor helpers (API surface; not on the fused hot loop)
+    def _beta_t(self, t):
+        return self.beta_0 + t * (self.beta_1 - self.beta_0)
+
+
+class _Reverse:
+    def __init__(self, fwd, score_fn, probability_flow):
+        self.fwd, self.score_fn, self.probability_flow, self.N = fwd, score_fn, probability_flow, fwd.N
+
+    @property
+    def T(self):
+        return self.fwd.T
+
+    def sde(self, x, t, cl_g=None, cl_s=None, target=None, given=None, all_mods=None):
+        if cl_g is not None and given:
+            raise NotImplementedError("classifier guidance is out of scope (SURVEY.md 8(f4))")
+        drift, diffusion = self.fwd.sde(x, t)
+        score = self.score_fn(x, t)
+        drift = drift - diffusion[:, None, None, None] ** 2 * score * (0.5 if self.probability_flow else 1.)
+        return drift, (torch.zeros_like(diffusion) if self.probability_flow else diffusion)
+
+    def discretize(self, x, t):
+        f, G = self.fwd.discretize(x, t)
+        rev_f = f - G[:, None, None, None] ** 2 * self.score_fn(x, t) * (0.5 if self.probability_flow else 1.)
+        return rev_f, (torch.zeros_like(G) if self.probability_flow else G)
+
+
+class VPSDE(SDE):
+    kind = 0
+
+    def __init__(self, beta_min=0.1, beta_max=20, N=1000):
+        super().__init__(N)
+        self.beta_0, self.beta_1 = beta_min, beta_max
+        self.discrete_betas = torch.linspace(beta_min / N, beta_max / N, N)
+        self.alphas = 1. - self.discrete_betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.sqrt_alphas_cumprod = torch.sqrt(self.alphas_cumprod)
+        self.sqrt_1m_alphas_cumprod = torch.sqrt(1. - self.alphas_cumprod)
+
+    def sde(self, x, t):
+        beta_t = self._beta_t(t)
+        return -0.5 * beta_t[:, None, None, None] * x, torch.sqrt(beta_t)
+
+    def marginal_prob(self, x, t):
+        lmc = -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        return torch.exp(lmc[:, None, None, None]) * x, torch.sqrt(1. - torch.exp(2. * lmc))
+
+    def discretize(self, x, t):
+        """DDPM discretisation (sde_helper2.py:372-381)."""
+        timestep = (t * (self.N - 1) / self.T).long()
+        beta = self.discrete_betas.to(x.device)[timestep]
+        alpha = self.alphas.to(x.device)[timestep]
+        return torch.sqrt(alpha)[:, None, None, None] * x - x, torch.sqrt(beta)
+
+
+class subVPSDE(SDE):
+    kind = 1
+
+    def __init__(self, beta_min=0.1, beta_max=20, N=1000):
+        super().__init__(N)
+        self.beta_0, self.beta_1 = beta_min, beta_max
+        # The reference's subVPSDE has no `.alphas`, so its corrector raises AttributeError; here the
+        # corrector uses the same table as VPSDE (as in score_sde_pytorch, which the reference adapts).
+        self.discrete_betas = torch.linspace(beta_min / N, beta_max / N, N)
+        self.alphas = 1. - self.discrete_betas
+
+    def sde(self, x, t):
+        beta_t = self._beta_t(t)
+        discount = 1. - torch.exp(-2 * self.beta_0 * t - (self.beta_1 - self.beta_0) * t ** 2)
+        return -0.5 * beta_t[:, None, None, None] * x, torch.sqrt(beta_t * discount)
+
+    def marginal_prob(self, x, t):
+        lmc = -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+        return torch.exp(lmc)[:, None, None, None] * x, 1 - torch.exp(2. * lmc)
+
+
+class VESDE(SDE):
+    kind = 2
+
+    def __init__(self, sigma_min=0.01, sigma_max=50, N=1000):
+        super().__init__(N)
+        self.sigma_min, self.sigma_max = sigma_min, sigma_max
+        self.beta_0, self.beta_1 = sigma_min, sigma_max
+        self.discrete_sigmas = torch.exp(torch.linspace(np.log(sigma_min), np.log(sigma_max), N))
+
+    def sde(self, x, t):
+        sigma = self.sigma_min * (self.sigma_max / self.sigma_min) ** t
+        return torch.zeros_like(x), sigma * math.sqrt(2 * (np.log(self.sigma_max) - np.log(self.sigma_min)))
+
+    def marginal_prob(self, x, t):
+        return x, self.sigma_min * (self.sigma_max / self.sigma_min) ** t
+
+    def prior_sampling(self, shape):
+        return torch.randn(*shape) * self.sigma_max
+
+    def prior_logp(self, z):
+        n = np.prod(z.shape[1:])
+        return -n / 2. * np.log(2 * np.pi * self.sigma_max ** 2) - torch.sum(z ** 2, dim=(1, 2, 3)) / (2 * self.sigma_max ** 2)
+
+    def discretize(self, x, t):
+        timestep = (t * (self.N - 1) / self.T).long()
+        sigma = self.discrete_sigmas.to(t.device)[timestep]
+        adjacent = torch.where(timestep == 0, torch.zeros_like(t), self.discrete_sigmas[timestep - 1].to(t.device))
+        return torch.zeros_like(x), torch.sqrt(sigma ** 2 - adjacent ** 2)
+
+
+# --------------------------------------------------------------------------------------------------
+def _no_guidance(cl_g, given=None):
+    if cl_g is not None and (given is None or given):
+        raise NotImplementedError("classifier / energy guidance (cl_g) is out of scope for this build (SURVEY.md 8(f4))")
+
+
+def _alphas_dev(sde, device):
+    if sde.kind == 2:
+        return None
+    cache = sde.__dict__.setdefault("_sbm_alphas", {})
+    key = str(device)
+    if key not in cache:
+        cache[key] = sde.alphas.to(device=device, dtype=torch.float32).contiguous()
+    return cache[key]
+
+
+def em_predictor(x, t, score_fn, sde, probability_flow=False, cl_g=None, cl_s=None, target=None, given=None,
+                 all_mods=None, *, noise=None, score=None):
+    """One reverse-SDE Euler-Maruyama step -> (x, x_mean)   [reference sde_helper2.py:45-52].
+
+    `noise`: the randn_like draw (default: torch.randn_like(x), drawn BEFORE the score call like the reference).
+    `score`: a precomputed score_fn(x, t) (skips the call)."""
+    _no_guidance(cl_g, given)
+    x = as_f32_cuda(x, "x")
+    t = as_f32_cuda(t, "t")
+    z = torch.randn_like(x) if noise is None else as_f32_cuda(noise, "noise")
+    s = as_f32_cuda(score_fn(x, t) if score is None else score, "score")
+    B = x.shape[0]
+    x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
+    cfg = sde._cfg(probability_flow=probability_flow)
+    _lib.check(_lib.lib().sbm_em_step(ctypes.byref(cfg), x.data_ptr(), s.data_ptr(), z.data_ptr(), t.data_ptr(),
+                                      x_new.data_ptr(), x_mean.data_ptr(), B, x[0].numel(), 0, 0, 0, _lib.stream_ptr()))
+    return x_new, x_mean
+
+
+def corrector(x, t, score_fn, sde, n_steps, target_snr, cl_g=None, cl_s=None, target=None, given=None, all_mods=None, *,
+              noise=None):
+    """n_steps Langevin corrector iterations -> (x, x_mean)   [reference sde_helper2.py:54-106].
+
+    `noise`: optional list of n_steps injected draws (default torch.randn_like after each score call)."""
+    _no_guidance(cl_g, given)
+    x = as_f32_cuda(x, "x")
+    t = as_f32_cuda(t, "t")
+    B = x.shape[0]
+    cfg = sde._cfg(target_snr=target_snr)
+    alphas = _alphas_dev(sde, x.device)
+    norms = torch.empty(2 * B, device=x.device, dtype=torch.float32)
+    x_mean = x
+    for i in range(n_steps):
+        g = as_f32_cuda(score_fn(x, t), "score")
+        z = torch.randn_like(x) if noise is None else as_f32_cuda(noise[i], "noise")
+        x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
+        _lib.check(_lib.lib().sbm_langevin_step(ctypes.byref(cfg), x.data_ptr(), g.data_ptr(), z.data_ptr(), t.data_ptr(),
+                                                alphas.data_ptr() if alphas is not None else None, x_new.data_ptr(),
+                                                x_mean.data_ptr(), norms.data_ptr(), B, x[0].numel(), 0, 0, 0, i,
+                                                _lib.stream_ptr()))
+        x = x_new
+    return x, x_mean
+
+
+def _fused_ok(model):
+    from .unet_model import Unet
+    return isinstance(model, Unet) and model.with_time_emb
+
+
+def uncond_sampler(sample_shape, model, device, sde, eps=1e-3, probability_flow=False, pc=False, n_steps=1,
+                   target_snr=0.16, cl_g=None, cl_s=None, target=None, *, order="cp", noise=None, x0=None, seed=None,
+                   sample_offset=0, use_graph=True, return_timing=False):
+    """N-step predictor(-corrector) sampling; returns the last sub-step's x_mean   [reference sde_helper2.py:115-128]."""
+    _no_guidance(cl_g)
+    if order not in ("cp", "pc"):
+        raise ValueError("order must be 'cp' (sde_helper2) or 'pc' (train_poly_unet_cont)")
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("uncond_sampler runs on the GPU only (no CPU path)")
+    with torch.no_grad():
+        x = (sde.prior_sampling(sample_shape) if x0 is None else x0).to(device=device, dtype=torch.float32).contiguous()
+        if x is x0:
+            x = x.clone()
+        timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
+        B = x.shape[0]
+        dps = 1 + (n_steps if pc else 0)
+        if noise is not None:
+            noise = as_f32_cuda(noise, "noise")
+            if noise.shape[0] < sde.N * dps:
+                raise ValueError(f"noise needs {sde.N * dps} draws")
+        if _fused_ok(model):
+            eng = model._engine_for(B, x.shape[2], x.shape[3])
+            cfg = sde._cfg(target_snr=target_snr, probability_flow=probability_flow)
+            if seed is None:
+                seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            scfg = _lib.SamplerCfg(int(bool(pc)), int(n_steps), 0 if order == "cp" else 1, int(bool(use_graph)),
+                                   int(seed), int(sample_offset))
+            alphas = _alphas_dev(sde, device) if pc else None
+            x_mean = torch.empty_like(x)
+            ms = ctypes.c_float(0.0)
+            _lib.check(_lib.lib().sbm_sampler_run(eng.h, ctypes.byref(cfg), ctypes.byref(scfg), timesteps.data_ptr(),
+                                                  alphas.data_ptr() if alphas is not None else None,
+                                                  noise.data_ptr() if noise is not None else None, x.data_ptr(),
+                                                  x_mean.data_ptr(), 0, sde.N, ctypes.byref(ms) if return_timing else None,
+                                                  _lib.stream_ptr()))
+            return (x_mean, ms.value) if return_timing else x_mean
+        # generic score_fn: Python loop over the HIP step kernels
+        k = 0
+        x_mean = x
+        for i in range(sde.N):
+            vec_t = torch.ones(B, device=device) * timesteps[i]
+
+            def corr(x):
+                nonlocal k
+                nz = None if noise is None else [noise[k + j] for j in range(n_steps)]
+                k += n_steps if noise is not None else 0
+                return corrector(x, vec_t, model, sde, n_steps, target_snr, noise=nz)
+
+            def pred(x):
+                nonlocal k
+                nz = None if noise is None else noise[k]
+                k += 1 if noise is not None else 0
+                return em_predictor(x, vec_t, model, sde, probability_flow, noise=nz)
+
+            if order == "cp":
+                if pc:
+                    x, x_mean = corr(x)
+                x, x_mean = pred(x)
+            else:
+                x, x_mean = pred(x)
+                if pc:
+                    x, x_mean = corr(x)
+        return x_mean

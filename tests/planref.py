@@ -40,6 +40,10 @@ def lib():
         L.sbmref_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.sbmref_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         L.sbmref_free.argtypes = [ctypes.c_void_p]
+        L.sbmref_run_range.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        L.sbmref_op_name.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
+        L.sbmref_workspace.restype = ctypes.POINTER(ctypes.c_float)
+        L.sbmref_workspace.argtypes = [ctypes.c_void_p]
         _lib = L
     return _lib
 
@@ -98,6 +102,19 @@ class RefPlan:
             tp = t.ctypes.data
         lib().sbmref_run(self.h, x.ctypes.data, tp, out.ctypes.data)
         return out
+
+    def run_range(self, x, t, out, first, last):
+        tp = t.ctypes.data if t is not None else None
+        lib().sbmref_run_range(self.h, x.ctypes.data, tp, out.ctypes.data, first, last)
+
+    def op_name(self, i):
+        buf = ctypes.create_string_buffer(256)
+        lib().sbmref_op_name(self.h, i, buf, 256)
+        return buf.value.decode()
+
+    def workspace(self):
+        """numpy view (no copy) of the interpreter's workspace."""
+        return np.ctypeslib.as_array(lib().sbmref_workspace(self.h), shape=(self.info["ws_floats"],))
 
     def __del__(self):
         if getattr(self, "h", None):

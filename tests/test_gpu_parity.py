@@ -1,0 +1,311 @@
+"""GPU parity: the HIP path (through the C ABI / the drop-in modules) against the golden fixtures
+produced by the real reference, against the oracle on seeded inputs, and -- at the bench
+configuration's full size -- through size-independent properties.
+
+Stated tolerances: per-forward rtol=1e-5, atol=1e-5*max|y|; N-step trajectories with
+injected noise rtol=1e-4, atol=1e-4*max|x|.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+UNET_CASES = {
+    "tiny": dict(dim=8, channels=2, dim_mults=(1, 2, 2, 2)),
+    "tiny2lvl": dict(dim=16, channels=3, dim_mults=(1, 2)),
+    "P2": dict(dim=64, channels=2, dim_mults=(1, 2, 2, 2)),
+    "P5": dict(dim=64, channels=5, dim_mults=(1, 2, 2, 2)),
+    "P10": dict(dim=128, channels=10, dim_mults=(1, 2, 2, 2)),
+    "C3": dict(dim=256, channels=3, dim_mults=(1, 2, 2, 2, 2)),
+}
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import score_based_multimodal_autoencoder_amd as P
+    from score_based_multimodal_autoencoder_amd import _lib, arch, h_vae_model, h_vae_model_copy, sde_helper2, synth, unet_model
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    _lib.lib()                     # fails loudly if the HIP library is missing: there is no fallback
+    return dict(lib=_lib, arch=arch, synth=synth, unet=unet_model, sde=sde_helper2, vae=h_vae_model_copy, attr=h_vae_model)
+
+
+def _unet(pkg, name):
+    c = UNET_CASES[name]
+    m = pkg["unet"].Unet(dim=c["dim"], channels=c["channels"], dim_mults=c["dim_mults"]).eval()
+    pkg["synth"].fill_module_(m)
+    return m.cuda()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ------------------------------------------------------------------------------------------------
+def test_no_cpu_path(pkg):
+    m = pkg["unet"].Unet(dim=8, channels=2, dim_mults=(1, 2))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 2, 4, 4), torch.zeros(1))
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny2lvl"])
+def test_unet_op_by_op_against_plan_interpreter(pkg, name, golden):
+    """Every plan op's output on the GPU vs the scalar host interpreter of the same descriptors."""
+    import planref
+    g = golden("unet_forward.npz")
+    c = UNET_CASES[name]
+    x, t = g[f"{name}_x"], g[f"{name}_t"]
+    sd = pkg["synth"].fill_state_dict(pkg["arch"].unet_state_shapes(**c))
+    cfg = pkg["lib"].unet_cfg_ints(c["dim"], c["channels"], c["dim_mults"], x.shape[2], x.shape[3])
+    B = x.shape[0]
+    ref = planref.RefPlan(0, cfg, B, sd)
+    eng = pkg["lib"].Engine(0, cfg, B, sd)
+    L = pkg["lib"].lib()
+    n_ws = L.sbm_debug_workspace_floats(eng.h)
+    assert n_ws == ref.info["ws_floats"]
+    xd, td = dev(x), dev(t)
+    out_d = torch.zeros(g[f"{name}_y"].shape, device="cuda")
+    out_h = np.zeros(g[f"{name}_y"].shape, np.float32)
+    ws_ref = ref.workspace()
+    host = np.empty(n_ws, np.float32)
+    for i in range(ref.info["n_ops"]):
+        before = ws_ref.copy()
+        ref.run_range(x, t, out_h, i, i + 1)
+        pkg["lib"].check(L.sbm_debug_forward_range(eng.h, xd.data_ptr(), td.data_ptr(), out_d.data_ptr(), i, i + 1, None))
+        pkg["lib"].check(L.sbm_debug_read_workspace(eng.h, 0, n_ws, host.ctypes.data))
+        changed = np.isfinite(ws_ref) & ~((ws_ref == before) & np.isfinite(before))
+        if not changed.any():
+            continue
+        want, got = ws_ref[changed], host[changed]
+        scale = max(np.abs(want).max(), 1e-6)
+        err = np.abs(got - want).max()
+        assert err <= 3e-5 * scale, f"op {i} ({ref.op_name(i)}): max err {err:.3e} vs scale {scale:.3e}"
+    assert_close(out_d.cpu().numpy(), out_h, 1e-5, 3e-5 * np.abs(out_h).max(), "final output")
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny2lvl", "P2", "P5", "P10", "C3"])
+def test_unet_forward_matches_reference(pkg, golden, name):
+    g = golden("unet_forward.npz")
+    m = _unet(pkg, name)
+    y = m(dev(g[f"{name}_x"]), dev(g[f"{name}_t"])).cpu().numpy()
+    want = g[f"{name}_y"]
+    assert_close(y, want, 1e-5, 1e-5 * np.abs(want).max(), name)
+
+
+def test_unet_integer_sigma_index_time(pkg, golden):
+    g = golden("unet_forward.npz")
+    m = _unet(pkg, "tiny")
+    y = m(dev(g["tiny_x"]), torch.from_numpy(g["tiny_ti"]).cuda()).cpu().numpy()
+    assert_close(y, g["tiny_yi"], 1e-5, 1e-5 * np.abs(g["tiny_yi"]).max(), "sigma index time")
+
+
+def test_unet_ragged_batch_and_padded_input(pkg):
+    from oracle import unet as OU
+    c = UNET_CASES["tiny"]
+    sd = pkg["synth"].fill_state_dict(pkg["arch"].unet_state_shapes(**c))
+    m = _unet(pkg, "tiny")
+    for shape in [(5, 2, 6, 6), (67, 2, 8, 8), (1, 2, 8, 8)]:
+        x = pkg["synth"].noise(3, shape[0], shape)
+        t = np.linspace(1.0, 1e-3, shape[0]).astype(np.float32)
+        want = OU.unet_forward(sd, x, t, **c)
+        assert_close(m(dev(x), dev(t)).cpu().numpy(), want, 1e-5, 1e-5 * np.abs(want).max(), str(shape))
+
+
+def test_unet_full_batch_matches_oracle(pkg):
+    """Config-2 shape: Unet(64, ch=5) at B=256 (128x128 / 128x64 tiles) vs the numpy oracle."""
+    from oracle import unet as OU
+    c = UNET_CASES["P5"]
+    sd = pkg["synth"].fill_state_dict(pkg["arch"].unet_state_shapes(**c))
+    m = _unet(pkg, "P5")
+    x = pkg["synth"].noise(11, 0, (256, 5, 8, 8))
+    t = np.linspace(1.0, 1e-3, 256).astype(np.float32)
+    y = m(dev(x), dev(t)).cpu().numpy()
+    want = OU.unet_forward(sd, x, t, **c)
+    assert_close(y, want, 1e-5, 1e-5 * np.abs(want).max(), "B=256")
+    # rows are independent: a 64-row sub-batch (different tile configuration) gives the same rows
+    y64 = m(dev(x[:64]), dev(t[:64])).cpu().numpy()
+    assert_close(y64, y[:64], 1e-6, 2e-6 * np.abs(want).max(), "sub-batch")
+    # load_state_dict with new weights invalidates the packed engine
+    sd2 = {k: torch.from_numpy(np.asarray(v)) * (0.5 if k.endswith("final_conv.1.weight") else 1.0) for k, v in sd.items()}
+    m.load_state_dict(sd2)
+    y2 = m(dev(x[:8]), dev(t[:8])).cpu().numpy()
+    assert not np.allclose(y2, y[:8])
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["ResVAE", "ResAE"])
+def test_poly_decoders(pkg, golden, name):
+    g = golden("decoders.npz")
+    A = pkg["arch"]
+    m = getattr(pkg["vae"], name)(A.POLY_ENC, A.POLY_DEC, 32, 64, 3).eval()
+    pkg["synth"].fill_module_(m)
+    m = m.cuda()
+    want = g[f"{name}_y"]
+    assert_close(m.decoder(dev(g[f"{name}_z"])).cpu().numpy(), want, 1e-5, 1e-5 * np.abs(want).max(), name)
+    if name == "ResVAE":
+        # the strided slice of the sampler state the reference decodes (train_poly_unet_cont.py:303)
+        from oracle import decoders as OD
+        sd = pkg["synth"].fill_state_dict(A.resvae_state_shapes(name, A.POLY_ENC, A.POLY_DEC, 32, 64, 3))
+        state = pkg["synth"].noise(5, 0, (6, 5, 8, 8))
+        zs = dev(state)[:, 3, :, :].view(6, 64)
+        assert zs.stride(0) == 320
+        want = OD.res_decoder(sd, state[:, 3].reshape(6, 64), A.POLY_ENC, A.POLY_DEC, 32, name)
+        assert_close(m.decoder(zs).cpu().numpy(), want, 1e-5, 1e-5 * np.abs(want).max(), "strided latents")
+        with pytest.raises(RuntimeError):
+            m.train().decoder(zs)
+
+
+@pytest.mark.parametrize("name,cls,enc,dec,ch", [("ResVAEN_img", "ResVAEN", "CEL_IMG_ENC", "CEL_IMG_DEC", 3),
+                                                 ("ResAEN_mask", "ResAEN", "CEL_MASK_ENC", "CEL_MASK_DEC", 1)])
+def test_celeba_decoders(pkg, golden, name, cls, enc, dec, ch):
+    g = golden("decoders.npz")
+    A = pkg["arch"]
+    m = getattr(pkg["vae"], cls)(getattr(A, enc), getattr(A, dec), 128, 256, ch).eval()
+    pkg["synth"].fill_module_(m)
+    m = m.cuda()
+    assert_close(m.decoder(dev(g[f"{name}_z"])).cpu().numpy(), g[f"{name}_y"], 1e-5, 1e-5, name)
+
+
+@pytest.mark.parametrize("name", ["AttrBN", "AttrBNAE"])
+def test_attr_decoders(pkg, golden, name):
+    g = golden("decoders.npz")
+    m = (pkg["attr"].CelebAAttrNewBN(256) if name == "AttrBN" else pkg["attr"].CelebAAttrNewBNAE(256)).eval()
+    pkg["synth"].fill_module_(m)
+    m = m.cuda()
+    want = g[f"{name}_y"]
+    assert_close(m.decoder(dev(g[f"{name}_z"])).cpu().numpy(), want, 1e-5, 1e-5 * np.abs(want).max(), name)
+
+
+# ------------------------------------------------------------------------------------------------
+SDE_TAGS = [("vp", 0.1, 5.0), ("vp", 1.0, 5.0), ("vp", 0.1, 20.0), ("subvp", 0.1, 20.0), ("ve", 0.01, 50.0)]
+
+
+def _sde(pkg, kind, b0, b1, N):
+    S = pkg["sde"]
+    return {"vp": S.VPSDE, "subvp": S.subVPSDE, "ve": S.VESDE}[kind](b0, b1, N)
+
+
+@pytest.mark.parametrize("kind,b0,b1", SDE_TAGS)
+@pytest.mark.parametrize("N", [100, 1000])
+def test_em_and_langevin_steps(pkg, golden, kind, b0, b1, N):
+    g = golden("sde_steps.npz")
+    S = pkg["sde"]
+    tag = f"{kind}_{b0}_{b1}_{N}"
+    sde = _sde(pkg, kind, b0, b1, N)
+    x, score, noise = dev(g["x"]), dev(g["score"]), dev(g["noise"])
+    for ti in (0, N // 2, N - 1):
+        vt = torch.ones(4, device="cuda") * float(g[tag + "_ts"][ti])
+        xn, xm = S.em_predictor(x, vt, lambda a, b: score, sde, noise=noise)
+        assert_close(xm.cpu().numpy(), g[f"{tag}_em{ti}_mean"], 2e-6, 2e-6, "em mean")
+        assert_close(xn.cpu().numpy(), g[f"{tag}_em{ti}_x"], 2e-6, 2e-6, "em x")
+        if kind != "subvp":
+            cn, cm = S.corrector(x, vt, lambda a, b: score, sde, 1, 0.16, noise=[noise])
+            assert_close(cm.cpu().numpy(), g[f"{tag}_co{ti}_mean"], 3e-6, 3e-6, "corrector mean")
+            assert_close(cn.cpu().numpy(), g[f"{tag}_co{ti}_x"], 3e-6, 3e-6, "corrector x")
+
+
+def _traj_noise(pkg, n_draws, shape):
+    return np.stack([pkg["synth"].noise(1234, k + 1, shape) for k in range(n_draws)])
+
+
+@pytest.mark.parametrize("tag", ["vp_cp_pc0", "vp_cp_pc1", "vp_pc_pc0", "vp_pc_pc1", "ve_cp_pc1"])
+@pytest.mark.parametrize("graph", [True, False])
+def test_fused_sampler_trajectory(pkg, golden, tag, graph):
+    """Config-1 shape (B=16, 2-mod, N=100): the whole loop in the HIP library with injected noise."""
+    g = golden("trajectories.npz")
+    S = pkg["sde"]
+    kind, order, pcs = tag.split("_")
+    pc = pcs == "pc1"
+    m = _unet(pkg, "P2")
+    sde = S.VPSDE(0.1, 5.0, 100) if kind == "vp" else S.VESDE(0.01, 5.0, 100)
+    shape = (16, 2, 8, 8)
+    x0 = pkg["synth"].noise(1234, 0, shape) * (np.float32(5.0) if kind == "ve" else np.float32(1.0))
+    noise = dev(_traj_noise(pkg, 100 * (2 if pc else 1), shape))
+    xm = S.uncond_sampler(shape, m, "cuda", sde, pc=pc, order=order, noise=noise, x0=torch.from_numpy(x0), use_graph=graph)
+    want = g[f"{tag}_mean99"]
+    assert_close(xm.cpu().numpy(), want, 1e-4, 1e-4 * np.abs(want).max(), tag)
+
+
+def test_generic_score_fn_loop(pkg, golden):
+    """uncond_sampler with an arbitrary score callable takes the Python loop over the HIP step kernels."""
+    g = golden("trajectories.npz")
+    S = pkg["sde"]
+    m = _unet(pkg, "P2")
+    shape = (16, 2, 8, 8)
+    noise = dev(_traj_noise(pkg, 200, shape))
+    xm = S.uncond_sampler(shape, lambda x, t: m(x, t), "cuda", S.VPSDE(0.1, 5.0, 100), pc=True, order="pc", noise=noise,
+                          x0=torch.from_numpy(pkg["synth"].noise(1234, 0, shape)))
+    want = g["vp_pc_pc1_mean99"]
+    assert_close(xm.cpu().numpy(), want, 1e-4, 1e-4 * np.abs(want).max(), "python loop")
+
+
+def test_reference_entry_point_replay(pkg, golden):
+    """The unmodified reference uncond_sampler under torch.manual_seed(7): its prior and its 20 draws replayed."""
+    g = golden("trajectories.npz")
+    S = pkg["sde"]
+    m = _unet(pkg, "P2")
+    xm = S.uncond_sampler((4, 2, 8, 8), m, "cuda", S.VPSDE(0.1, 5.0, 20), noise=dev(g["ref_uncond_seed7_noise"]),
+                          x0=torch.from_numpy(g["ref_uncond_seed7_prior"]))
+    want = g["ref_uncond_seed7"]
+    assert_close(xm.cpu().numpy(), want, 1e-4, 1e-4 * np.abs(want).max(), "uncond_sampler")
+    # same host prior as the reference when nothing is injected
+    torch.manual_seed(7)
+    a = S.VPSDE(0.1, 5.0, 20).prior_sampling((4, 2, 8, 8)).numpy()
+    np.testing.assert_array_equal(a, g["ref_uncond_seed7_prior"])
+
+
+# ------------------------------------------------------------------------------------------------
+def test_philox_normals(pkg):
+    L = pkg["lib"]
+    out = torch.empty(64, 4096, device="cuda")
+    L.check(L.lib().sbm_fill_normal(out.data_ptr(), 4096, 64, 42, 0, 3, 0, 1.0, None))
+    a = out.cpu().numpy().astype(np.float64)
+    assert abs(a.mean()) < 0.01 and abs(a.var() - 1.0) < 0.02
+    assert abs(np.mean(a ** 3)) < 0.05 and abs(np.mean(a ** 4) - 3.0) < 0.1
+    # keyed by the GLOBAL sample index: rows [32, 64) equal a second call with sample_offset=32
+    out2 = torch.empty(32, 4096, device="cuda")
+    L.check(L.lib().sbm_fill_normal(out2.data_ptr(), 4096, 32, 42, 32, 3, 0, 1.0, None))
+    assert torch.equal(out[32:], out2)
+    # different step / draw / seed -> decorrelated
+    for args in [(42, 0, 4, 0), (42, 0, 3, 1), (43, 0, 3, 0)]:
+        o = torch.empty(64, 4096, device="cuda")
+        L.check(L.lib().sbm_fill_normal(o.data_ptr(), 4096, 64, args[0], args[1], args[2], args[3], 1.0, None))
+        assert abs(float((o * out).mean())) < 0.01
+
+
+def test_sampler_determinism_and_sharding_invariance(pkg):
+    """Bench-size properties (B=256, 5-mod): same seed -> same bits; splitting the batch over 'ranks'
+    with sample_offset reproduces the unsharded rows exactly (EM-only has no cross-sample coupling)."""
+    S = pkg["sde"]
+    m = _unet(pkg, "P5")
+    sde = S.VPSDE(0.1, 5.0, 1000)
+    short = S.VPSDE(0.1, 5.0, 25)
+    shape = (256, 5, 8, 8)
+    x0 = torch.from_numpy(pkg["synth"].noise(9, 0, shape))
+    a = S.uncond_sampler(shape, m, "cuda", short, x0=x0, seed=123)
+    b = S.uncond_sampler(shape, m, "cuda", short, x0=x0, seed=123)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    c = S.uncond_sampler(shape, m, "cuda", short, x0=x0, seed=124)
+    assert not torch.equal(a, c)
+    parts = [S.uncond_sampler((128, 5, 8, 8), m, "cuda", short, x0=x0[r * 128:(r + 1) * 128], seed=123, sample_offset=r * 128)
+             for r in range(2)]
+    assert_close(torch.cat(parts).cpu().numpy(), a.cpu().numpy(), 1e-5, 1e-5 * float(a.abs().max()), "2-way shard")
+    # the full 1000-step configuration runs and stays finite
+    full = S.uncond_sampler(shape, m, "cuda", sde, x0=x0, seed=5)
+    assert torch.isfinite(full).all()
+
+
+def test_c_abi_error_paths(pkg):
+    L = pkg["lib"]
+    lib = L.lib()
+    cfg = L.SdeCfg(0, 0.1, 5.0, 100, 0.16, 0)
+    rc = lib.sbm_em_step(ctypes.byref(cfg), None, None, None, None, None, None, 4, 128, 0, 0, 0, None)
+    assert rc != 0 and b"bad arguments" in lib.sbm_last_error()
+    with pytest.raises(RuntimeError):
+        L.Engine(0, L.unet_cfg_ints(8, 2, (1, 2, 2, 2, 2, 2), 8, 8), 2,
+                 pkg["synth"].fill_state_dict(pkg["arch"].unet_state_shapes(dim=8, channels=2, dim_mults=(1, 2, 2, 2, 2, 2))))

@@ -1,0 +1,167 @@
+"""Host-side logic that needs no GPU: the drop-in modules' state_dict surface, the C-ABI library's
+exported symbols, loud failure without a GPU, the SDE objects' scalar API, the CPU-baseline port, and
+the world_size-2 sharding path over gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, assert_close
+from score_based_multimodal_autoencoder_amd import _lib, arch, synth
+from score_based_multimodal_autoencoder_amd import sde_helper2 as S
+from score_based_multimodal_autoencoder_amd.h_vae_model import CelebAAttrNewBN, CelebAAttrNewBNAE
+from score_based_multimodal_autoencoder_amd.h_vae_model_copy import ResAE, ResAEN, ResVAE, ResVAEN
+from score_based_multimodal_autoencoder_amd.unet_model import Unet
+
+
+def _shapes(m):
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def test_unet_state_dict_surface():
+    m = Unet(dim=64, channels=5, dim_mults=(1, 2, 2, 2), with_time_emb=True)
+    want = {k: tuple(s) for k, s in arch.unet_entries(dim=64, channels=5, dim_mults=(1, 2, 2, 2))}
+    assert _shapes(m) == want and list(m.state_dict()) == list(want)
+    assert sum(p.numel() for p in m.parameters()) == 10_964_947          # P5 parameter count
+    assert len(m.state_dict()) == 286
+    # load_state_dict round trip with the reference's key names
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(want).items()}
+    m.load_state_dict(sd)
+    assert torch.equal(m.state_dict()["downs.1.2.fn.fn.to_out.1.weight"], sd["downs.1.2.fn.fn.to_out.1.weight"])
+    with pytest.raises(NotImplementedError):
+        Unet(dim=8, use_convnext=False)
+
+
+def test_decoder_state_dict_surface():
+    for cls, v, enc, dec, ch, s, z in [(ResVAE, "ResVAE", arch.POLY_ENC, arch.POLY_DEC, 3, 32, 64),
+                                       (ResAE, "ResAE", arch.POLY_ENC, arch.POLY_DEC, 3, 32, 64),
+                                       (ResVAEN, "ResVAEN", arch.CEL_IMG_ENC, arch.CEL_IMG_DEC, 3, 128, 256),
+                                       (ResAEN, "ResAEN", arch.CEL_MASK_ENC, arch.CEL_MASK_DEC, 1, 128, 256)]:
+        m = cls(enc, dec, s, z, ch)
+        assert _shapes(m) == {k: tuple(sh) for k, sh in arch.resvae_entries(v, enc, dec, s, z, ch)}
+    assert _shapes(CelebAAttrNewBN(256)) == {k: tuple(s) for k, s in arch.attr_entries(256)}
+    assert _shapes(CelebAAttrNewBNAE(256)) == {k: tuple(s) for k, s in arch.attr_entries(256, ae=True)}
+
+
+def test_library_exports_every_declared_symbol():
+    _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    header = open(os.path.join(ROOT, "include", "sbmae.h")).read()
+    declared = sorted(set(re.findall(r"\b(sbm_[a-z_0-9]+)\s*\(", header)))
+    assert len(declared) >= 15
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/sbmae.h but not exported"
+    assert set(_lib.EXPORTS) <= set(declared)
+    assert L.sbm_abi_version() == 1
+    # the spec tables are host-only: usable without a GPU, and identical to the Python arch tables
+    cfg = _lib.unet_cfg_ints(64, 5, (1, 2, 2, 2), 8, 8)
+    assert _lib.specs(_lib.SBM_UNET, cfg) == [(k, int(np.prod(s))) for k, s in arch.unet_entries(dim=64, channels=5, dim_mults=(1, 2, 2, 2))]
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_compute_fails_loudly_without_gpu():
+    m = Unet(dim=8, channels=2, dim_mults=(1, 2))
+    with pytest.raises(RuntimeError, match="no CPU path|GPU"):
+        m(torch.zeros(1, 2, 4, 4), torch.zeros(1))
+    with pytest.raises(RuntimeError):
+        ResVAE(arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3).eval().decoder(torch.zeros(2, 64))
+    with pytest.raises(RuntimeError):
+        S.uncond_sampler((2, 2, 8, 8), m, "cpu", S.VPSDE(0.1, 5, 10))
+    with pytest.raises(RuntimeError):
+        _lib.Engine(_lib.SBM_UNET, _lib.unet_cfg_ints(8, 2, (1, 2), 4, 4), 1,
+                    synth.fill_state_dict(arch.unet_state_shapes(dim=8, channels=2, dim_mults=(1, 2))))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "score_based_multimodal_autoencoder_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+            assert "planref" not in src, f
+
+
+@pytest.mark.parametrize("kind,b0,b1", [("vp", 0.1, 5.0), ("vp", 0.1, 20.0), ("subvp", 0.1, 20.0), ("ve", 0.01, 50.0)])
+def test_sde_objects_scalar_api(golden, kind, b0, b1):
+    g = golden("sde_steps.npz")
+    N = 1000
+    tag = f"{kind}_{b0}_{b1}_{N}"
+    sde = {"vp": S.VPSDE, "subvp": S.subVPSDE, "ve": S.VESDE}[kind](b0, b1, N)
+    ts = torch.from_numpy(g[tag + "_ts"])
+    drift, diff = sde.sde(torch.ones(N, 1, 1, 1), ts)
+    assert_close(drift.reshape(N).numpy(), g[tag + "_dcoef"], 1e-6, 0, "drift")
+    assert_close(np.asarray(diff), g[tag + "_g"], 1e-6, 1e-9, "diffusion")
+    mean, std = sde.marginal_prob(torch.ones(N, 1, 1, 1), ts)
+    assert_close(mean.reshape(N).numpy(), g[tag + "_mpmean"], 1e-6, 0, "marginal mean")
+    assert_close(np.asarray(std), g[tag + "_mpstd"], 1e-6, 1e-9, "marginal std")
+    assert sde.T == 1 and sde.N == N
+    if kind == "vp":
+        np.testing.assert_array_equal(sde.alphas[torch.from_numpy(g[tag + "_aidx"])].numpy(), g[tag + "_alpha"])
+    assert tuple(sde.prior_sampling((3, 2, 8, 8)).shape) == (3, 2, 8, 8)
+    with pytest.raises(NotImplementedError):
+        S.em_predictor(torch.zeros(1), torch.zeros(1), None, sde, cl_g=object(), given="0", all_mods="01")
+
+
+def test_cpu_baseline_port_matches_reference(golden):
+    """oracle/torch_port.py (the cpu_baseline leg of bench.py) against the reference's outputs."""
+    from oracle import torch_port as TP
+    g = golden("unet_forward.npz")
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(
+        arch.unet_state_shapes(dim=64, channels=5, dim_mults=(1, 2, 2, 2))).items()}
+    with torch.no_grad():
+        y = TP.unet_forward(sd, torch.from_numpy(g["P5_x"]), torch.from_numpy(g["P5_t"]), 64, 4).numpy()
+    assert_close(y, g["P5_y"], 1e-5, 1e-5 * np.abs(g["P5_y"]).max(), "torch port Unet")
+    d = golden("decoders.npz")
+    dsd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(
+        arch.resvae_state_shapes("ResVAE", arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3)).items()}
+    with torch.no_grad():
+        img = TP.poly_decoder(dsd, torch.from_numpy(d["ResVAE_z"]), arch.POLY_DEC).numpy()
+    assert_close(img, d["ResVAE_y"], 1e-5, 1e-5 * np.abs(d["ResVAE_y"]).max(), "torch port decoder")
+    s = golden("sde_steps.npz")
+    ts = float(s["vp_0.1_5.0_100_ts"][50])
+    xn, xm = TP.vp_em_step(torch.from_numpy(s["x"]), torch.ones(4) * ts, torch.from_numpy(s["score"]), torch.from_numpy(s["noise"]), 0.1, 5.0, 100)
+    assert_close(xn.numpy(), s["vp_0.1_5.0_100_em50_x"], 1e-6, 1e-6, "torch port em step")
+
+
+_WORKER = r"""
+import os, sys, torch
+sys.path.insert(0, sys.argv[1])
+from score_based_multimodal_autoencoder_amd import distributed as D
+rank, world = D.init_from_env("gloo")
+assert world == 2
+G = 12
+def sample_fn(start, count):           # a pure function of the GLOBAL row index, like the Philox-keyed sampler
+    rows = torch.arange(start, start + count, dtype=torch.float32)
+    return rows[:, None, None].expand(count, 2, 3) * 1.5 + 1.0, rows[:, None] * torch.ones(1, 5)
+a, b = D.sample_sharded(sample_fn, G)
+ra, rb = sample_fn(0, G)
+assert torch.equal(a, ra) and torch.equal(b, rb), "gathered result differs from the unsharded one"
+assert D.shard_range(G, rank, world) == (rank * 6, 6)
+s = D.langevin_norm_allreduce(torch.tensor([1.0 + rank, 2.0]))
+assert torch.equal(s, torch.tensor([3.0, 4.0]))
+try:
+    D.shard_range(13, rank, world); raise SystemExit("uneven split accepted")
+except ValueError:
+    pass
+torch.distributed.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_sharding_over_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r} failed:\n{o}"
+        assert f"rank {r} ok" in o
