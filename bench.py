@@ -32,6 +32,41 @@ N_MOD, N_SDE, B_PER_GPU = 5, 1000, 256
 BETA = (0.1, 5.0)
 
 
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box gives
+    one GPU's share of a big host; running one thread per HOST core would oversubscribe it badly)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(p)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota:
+        n = min(n, max(1, int(quota)))
+    elif n > 16:
+        n = 16                                   # documented share of a 1-GPU box
+    return int(os.environ.get("SBM_CPU_THREADS", n))
+
+
 def build_models(device):
     from score_based_multimodal_autoencoder_amd import arch, synth
     from score_based_multimodal_autoencoder_amd.h_vae_model_copy import ResVAE
@@ -56,12 +91,9 @@ def cpu_baseline(n_steps=10):
     reference on CPU), B=256, n_steps SDE steps + the 5 decoders, extrapolated linearly to 1000 steps."""
     from oracle import torch_port as TP
     from score_based_multimodal_autoencoder_amd import arch, synth
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads, {n_steps} SDE steps at B={B_PER_GPU}")
     sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(
         arch.unet_state_shapes(dim=64, channels=N_MOD, dim_mults=(1, 2, 2, 2))).items()}
     dsd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(
@@ -106,6 +138,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
+    log(f"rank {rank}/{world}: building models")
     score, decs = build_models(device)
     sde = VPSDE(BETA[0], BETA[1], N_SDE)
     start = rank * B_PER_GPU
@@ -127,6 +160,7 @@ def main():
 
     for w in range(args.warmup):
         job(100 + w)
+        log(f"warm-up pass {w} done")
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -138,6 +172,7 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(tmax.item())
     assert torch.isfinite(out).all()
+    log(f"timed {args.steps} passes in {elapsed:.3f} s")
 
     if rank == 0:
         value = world * B_PER_GPU * args.steps / elapsed
@@ -155,6 +190,7 @@ def main():
         tt = torch.ones(B_PER_GPU, device=device) * 0.5
         so = torch.empty_like(xs)
         prof = eng.profile(xs, tt, so, reps=20)
+        log("per-kernel profile done")
         gemm = prof["seg_gemm"]
         flops = eng.info["flops_dense_gemm"]
         achieved = flops / (gemm["ms"] * 1e-3) / 1e12 if gemm["ms"] > 0 else 0.0

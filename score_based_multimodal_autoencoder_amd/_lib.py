@@ -20,7 +20,7 @@ OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "n
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
            "sbm_model_info", "sbm_model_forward", "sbm_model_profile", "sbm_em_step", "sbm_langevin_step",
            "sbm_fill_normal", "sbm_sampler_run", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
-           "sbm_debug_read_workspace", "sbm_debug_op_name"]
+           "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps"]
 
 
 class SdeCfg(ctypes.Structure):
@@ -88,6 +88,8 @@ def lib():
         L.sbm_debug_workspace_floats.argtypes = [vp]
         L.sbm_debug_read_workspace.argtypes = [vp, ctypes.c_long, ctypes.c_long, vp]
         L.sbm_debug_op_name.argtypes = [vp, i, ctypes.c_char_p, i]
+        L.sbm_debug_gemm_stamps.argtypes = [vp, vp, vp, i, ctypes.POINTER(ctypes.c_uint64)]
+        L.sbm_debug_profile_ops.argtypes = [vp, vp, vp, vp, i, ctypes.POINTER(dbl), ctypes.POINTER(dbl), i]
         _lib = L
         return L
 

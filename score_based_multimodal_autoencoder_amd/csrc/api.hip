@@ -167,6 +167,21 @@ int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_de
   HIPCHK(hipStreamSynchronize(st));
   return 0;
 }
+// run op `i` alone with the diagnostic stamp buffer armed; stamps[0..7] = cycles {prologue, loop, epilogue, wait, issue,
+// compute} of the middle block's wave 0, chunk count, grid size
+int sbm_debug_gemm_stamps(sbm_model* m, const float* in_dev, float* out_dev, int i, unsigned long long* stamps_host) {
+  if (!m || i < 0 || i >= (int)m->plan.ops.size() || m->plan.ops[i].kind != OP_GEMM) return fail("sbm_debug_gemm_stamps: not a GEMM op");
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc(&d, 64)); HIPCHK(hipMemset(d, 0, 64));
+  g_gemm_dbg = d;
+  const char* e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, m->own);
+  g_gemm_dbg = nullptr;
+  if (e) return fail(e);
+  HIPCHK(hipStreamSynchronize(m->own));
+  HIPCHK(hipMemcpy(stamps_host, d, 64, hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return 0;
+}
 long sbm_debug_workspace_floats(const sbm_model* m) { return m ? (long)m->plan.ws_floats : -1; }
 int sbm_debug_read_workspace(sbm_model* m, long off, long n, float* host) {
   if (!m || !host || off < 0 || off + n > (long)m->plan.ws_floats) return fail("sbm_debug_read_workspace: bad range");
@@ -178,6 +193,31 @@ int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap) {
   if (!m || i < 0 || i >= (int)m->plan.ops.size() || cap <= 0) return fail("sbm_debug_op_name: bad index");
   std::string s = std::to_string(m->plan.ops[i].kind) + ":" + m->plan.ops[i].name;
   std::strncpy(name, s.c_str(), cap - 1); name[cap - 1] = 0;
+  return 0;
+}
+
+// per-op variant of sbm_model_profile: ms_per_op[i], flops_per_op[i], grid_per_op[i] for i < n_ops
+int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, double* ms_per_op, double* flops_per_op, int n_ops) {
+  if (!m || !in_dev || !out_dev || reps <= 0 || !ms_per_op) return fail("sbm_debug_profile_ops: bad arguments");
+  hipStream_t st = m->own;
+  const char* e = run_plan(m->plan, m->d_params, m->d_ws, in_dev, t_dev, out_dev, st);
+  if (e) return fail(e);
+  HIPCHK(hipStreamSynchronize(st));
+  const size_t nops = m->plan.ops.size();
+  std::vector<hipEvent_t> ev(nops + 1);
+  for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+  for (int i = 0; i < n_ops; ++i) { ms_per_op[i] = 0; if (flops_per_op) flops_per_op[i] = i < (int)nops ? m->plan.ops[i].flops : 0; }
+  for (int r = 0; r < reps; ++r) {
+    HIPCHK(hipEventRecord(ev[0], st));
+    for (size_t i = 0; i < nops; ++i) {
+      e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, st);
+      if (e) return fail(e);
+      HIPCHK(hipEventRecord(ev[i + 1], st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < nops && (int)i < n_ops; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); ms_per_op[i] += ms / reps; }
+  }
+  for (auto& x : ev) (void)hipEventDestroy(x);
   return 0;
 }
 

@@ -15,6 +15,8 @@ const char* run_plan(const Plan& plan, const float* params_dev, float* ws_dev, c
 const char* launch_op(const Plan& plan, const Op& op, const float* params_dev, float* ws_dev, const float* ext_in, float* ext_out,
                       hipStream_t st);
 
+extern unsigned long long* g_gemm_dbg;
+
 // SDE description shared by the step kernels (mirrors oracle/sde.py SDECfg)
 struct SdeParams {
   int kind;          // 0 VP, 1 subVP, 2 VE

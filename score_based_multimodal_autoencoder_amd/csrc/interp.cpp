@@ -76,12 +76,12 @@ static void run_gemm(const GemmOp& g, const float* prm, float* ws, const float* 
       for (int n = 0; n < nstore; ++n) {
         float acc = 0.f;
         for (size_t t = 0; t < taps.size(); ++t) {
-          const float* w = W + ((int64_t)taps[t] * g.Npad + n) * g.a.C;
+          const float* w = W + ((int64_t)taps[t] * g.Npad + n) * g.Kp;
           const float* a = &arow[t * g.a.C];
           for (int k = 0; k < g.a.C; ++k) acc = std::fmaf(a[k], w[k], acc);
         }
         if (g.has2) {
-          const float* w2 = prm + g.w2_off + (int64_t)n * g.a2.C;
+          const float* w2 = prm + g.w2_off + (int64_t)n * g.Kp2;
           for (int k = 0; k < g.a2.C; ++k) acc = std::fmaf(a2[k], w2[k], acc);
         }
         float v = acc;

@@ -32,13 +32,13 @@ DEVINL float act_apply(int act, float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// seg_gemm
+// seg_gemm  (LDS-DMA ring)
 // ------------------------------------------------------------------------------------------------
 struct GemmArgs {
   const float* A;      // source 1 base (already offset to the view origin)
-  const float* W;      // [tap][Npad][Ca]
+  const float* W;      // [tap][Npad][Kp]
   const float* A2;     // source 2 base or null
-  const float* W2;     // [Npad][C2]
+  const float* W2;     // [Npad][Kp2]
   const float* bias;   // [Npad] or null
   const float* R;      // residual base or null
   float* out;          // PBC view origin, or NCHW base
@@ -46,136 +46,229 @@ struct GemmArgs {
   float2* stat_out;
   long long w_pix_stride, bias_pix_stride;
   int B, Hout, Wout;
-  int lda, Ca, Ha, Wa, up, KH, KW, stride, pad, transposed, a_bcast;
+  int lda, Kp, Ha, Wa, up, KH, KW, stride, pad, transposed, a_bcast;
   int gn_nparts; float gn_inv_count;
-  int lda2, C2, W2w, up2;
-  int ldr, Wr;
+  int lda2, Kp2, W2w, up2;
+  int ldr;
   int act, ldo, nstore, Npad, out_nchw, N, crop_y, crop_x, Hn, Wn;
   int mtiles, ntiles;
+  unsigned long long* dbg;   // diagnostic build only: cycle stamps of one block's wave 0 (null in production)
 };
 
-constexpr int BK = 32;        // K chunk
-constexpr int LDS_LD = 36;    // padded LDS row stride (floats): conflict-free ds_read_b128 / ds_write_b128
+constexpr int BK = 32;        // K chunk = one 128-byte LDS row per operand row
 
-template <int BM, int BN>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+// Fragment reads are inline asm: hipcc must not see an LDS read while LDS-DMA is in flight, or it drains the
+// whole ring (s_waitcnt vmcnt(0)) in front of it.  `lds_issue` starts N ds_read_b128, `lds_wait` is the
+// matching s_waitcnt lgkmcnt(0) that names every destination "+v" (cdna_hip_programming.md 5.7 item 1, form (ii)),
+// so that the MFMAs consuming them cannot be scheduled above the wait and the next group's reads can be
+// issued before the current group's MFMAs.  Outputs are early-clobber: a destination must not share a register
+// with the address of a later read of the same statement (the data may land before that read issues).
+template <int N> DEVINL void lds_issue(f32x4* o, const unsigned* a);
+template <> DEVINL void lds_issue<4>(f32x4* o, const unsigned* a) {
+  asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]) : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+}
+template <> DEVINL void lds_issue<6>(f32x4* o, const unsigned* a) {
+  asm volatile("ds_read_b128 %0, %6\n\tds_read_b128 %1, %7\n\tds_read_b128 %2, %8\n\tds_read_b128 %3, %9\n\tds_read_b128 %4, %10\n\tds_read_b128 %5, %11"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]) : "memory");
+}
+template <> DEVINL void lds_issue<8>(f32x4* o, const unsigned* a) {
+  asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %9\n\tds_read_b128 %2, %10\n\tds_read_b128 %3, %11\n\t"
+               "ds_read_b128 %4, %12\n\tds_read_b128 %5, %13\n\tds_read_b128 %6, %14\n\tds_read_b128 %7, %15"
+               : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]) : "memory");
+}
+template <> DEVINL void lds_issue<10>(f32x4* o, const unsigned* a) { lds_issue<4>(o, a); lds_issue<6>(o + 4, a + 4); }
+template <> DEVINL void lds_issue<12>(f32x4* o, const unsigned* a) { lds_issue<6>(o, a); lds_issue<6>(o + 6, a + 6); }
+
+template <int N> DEVINL void lds_wait(f32x4* o);
+template <> DEVINL void lds_wait<4>(f32x4* o) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3])::"memory"); }
+template <> DEVINL void lds_wait<6>(f32x4* o) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5])::"memory");
+}
+template <> DEVINL void lds_wait<8>(f32x4* o) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7])::"memory");
+}
+template <> DEVINL void lds_wait<10>(f32x4* o) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(o[8]), "+v"(o[9])::"memory");
+}
+template <> DEVINL void lds_wait<12>(f32x4* o) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(o[0]), "+v"(o[1]), "+v"(o[2]), "+v"(o[3]), "+v"(o[4]), "+v"(o[5]), "+v"(o[6]), "+v"(o[7]), "+v"(o[8]), "+v"(o[9]),
+               "+v"(o[10]), "+v"(o[11])::"memory");
+}
+template <int N> DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Walk over the K chunks of one output pixel: valid taps of source 1 (Kp / 32 chunks each), then source 2.
+// All state is wave-uniform; no integer division anywhere.
+struct ChunkWalk {
+  int seg;        // 0: source 1, 1: source 2, 2: exhausted
+  int t, ky, kx;  // current tap of source 1
+  int q;          // its source pixel
+  int kc;         // K offset inside the current tap / inside source 2
+};
+
+DEVINL void walk_next_tap(const GemmArgs& g, ChunkWalk& w, int oy, int ox) {
+  const int ntaps = g.KH * g.KW;
+  for (;;) {
+    ++w.t; ++w.kx;
+    if (w.kx == g.KW) { w.kx = 0; ++w.ky; }
+    if (w.t >= ntaps) { w.seg = g.A2 ? 1 : 2; w.kc = 0; return; }
+    const int q = g.a_bcast ? 0 : tap_source_pixel(oy, ox, w.ky, w.kx, g.stride, g.pad, g.transposed, g.up, g.Ha, g.Wa);
+    if (q >= 0) { w.q = q; w.kc = 0; return; }
+  }
+}
+DEVINL void walk_init(const GemmArgs& g, ChunkWalk& w, int oy, int ox) {
+  w.seg = 0; w.t = -1; w.ky = 0; w.kx = -1; w.q = 0; w.kc = 0;
+  walk_next_tap(g, w, oy, ox);
+}
+DEVINL void walk_advance(const GemmArgs& g, ChunkWalk& w, int oy, int ox) {
+  w.kc += BK;
+  if (w.seg == 0) { if (w.kc >= g.Kp) walk_next_tap(g, w, oy, ox); }
+  else if (w.kc >= g.Kp2) w.seg = 2;
+}
+
+// One workgroup = 4 waves (2 x 2) computing out[p][m0:m0+BM][n0:n0+BN].
+//
+// LDS ring of NST stages; a stage holds one K chunk: BM A rows + BN B rows of 128 bytes, filled by LDS-DMA
+// (global_load_lds_dwordx4: each wave-instruction writes 1 KiB = 8 rows).  Rows are unpadded -- the DMA write is
+// lane-linear -- so the 16-byte slots of a row are XOR-swizzled by (row >> 1) & 7 on the SOURCE address and on the
+// fragment read, which makes ds_read_b128 conflict-free.  With GroupNorm a stage also holds one private 256-byte
+// {gamma, beta} copy per wave, and the normalisation is applied to the A fragments in registers.
+// Every wave issues the same number IA of DMA instructions per chunk, so `s_waitcnt vmcnt((NST-2)*IA)` retires
+// exactly chunk i while NST-2 younger chunks stay in flight across the (raw) barrier.
+// Rows beyond the batch / beyond Npad are CLAMPED, K is padded to 32 with zero weights: the loop has no predicate.
+template <int BM, int BN, int NST, bool GN>
 __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
-  constexpr int WM = BM / 64, WN = BN / 64;      // 32x32 MFMA tiles per wave in M and N (waves are 2 x 2)
-  constexpr int RA = BM / 32, RB = BN / 32;      // float4 staging loads per thread for A and B
-  __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * LDS_LD];
-  __shared__ int s_tap[64], s_src[64];
-  __shared__ int s_nvalid;
+  constexpr int WM = BM / 64, WN = BN / 64;          // 32x32 MFMA tiles per wave in M and N (waves are 2 x 2)
+  constexpr int ROWS = BM + BN;
+  constexpr int NI = ROWS / 32;                      // DMA wave-instructions per wave per chunk (8 rows each)
+  constexpr int RA = BM / 32;                        // the first RA of them carry A rows
+  constexpr int STAGE_F = ROWS * 32 + (GN ? 4 * 64 : 0);
+  constexpr int IA = NI + (GN ? 1 : 0);
+  constexpr int PER = WM + WN + (GN ? 2 : 0);        // ds_read_b128 per k-group of 8
+  constexpr int NRD = 2 * PER;                       // ... per asm statement (two k-groups)
+  constexpr int EP_LD = 32 * WN + 4;                 // epilogue transpose tile row stride (floats)
+  constexpr int LDS_F = NST * STAGE_F > 4 * 32 * EP_LD + 4 * BM ? NST * STAGE_F : 4 * 32 * EP_LD + 4 * BM;
+  __shared__ __attribute__((aligned(1024))) float lds[LDS_F];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave >> 1, wave_n = wave & 1;
+  unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_wait = 0, st_issue = 0, st_comp = 0, st_a = 0, st_b = 0;
+  if (g.dbg) st_t0 = __builtin_amdgcn_s_memtime();
   int bid = blockIdx.x;
   const int nt = bid % g.ntiles; bid /= g.ntiles;
   const int mt = bid % g.mtiles; const int p = bid / g.mtiles;
   const int m0 = mt * BM, n0 = nt * BN;
   const int oy = p / g.Wout, ox = p - oy * g.Wout;
+  const int fi = lane & 31, fh = lane >> 5;
 
-  // ---- valid taps of this output pixel (wave 0 compacts them with a ballot) ----
-  if (wave == 0) {
-    const int ntaps = g.KH * g.KW;
-    int q = -1;
-    if (lane < ntaps) {
-      const int ky = lane / g.KW, kx = lane - ky * g.KW;
-      q = g.a_bcast ? 0 : tap_source_pixel(oy, ox, ky, kx, g.stride, g.pad, g.transposed, g.up, g.Ha, g.Wa);
-    }
-    const unsigned long long mask = __ballot(q >= 0);
-    if (q >= 0) {
-      const int pos = __popcll(mask & ((1ull << lane) - 1ull));
-      s_tap[pos] = lane; s_src[pos] = q;
-    }
-    if (lane == 0) s_nvalid = __popcll(mask);
-  }
-
-  // ---- staging role of this thread: rows sr + 32*j, k offset skq ----
-  const int sr = tid >> 3, skq = (tid & 7) * 4;
-
-  // ---- GroupNorm(1,C) statistics of my A rows from the producer's partial sums ----
-  float gmean[RA], grstd[RA];
-#pragma unroll
-  for (int j = 0; j < RA; ++j) { gmean[j] = 0.f; grstd[j] = 1.f; }
-  if (g.gn_part) {
-#pragma unroll
-    for (int j = 0; j < RA; ++j) {
-      const int b = m0 + sr + 32 * j;
-      double s = 0.0, q = 0.0;
-      if (b < g.B)
-        for (int i = (tid & 7); i < g.gn_nparts; i += 8) { const float2 v = g.gn_part[(long long)i * g.B + b]; s += v.x; q += v.y; }
-#pragma unroll
-      for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-      const double mean = s * (double)g.gn_inv_count;
-      double var = q * (double)g.gn_inv_count - mean * mean;
-      var = var < 0.0 ? 0.0 : var;
-      gmean[j] = (float)mean; grstd[j] = (float)(1.0 / sqrt(var + 1e-5));
+  // ---- chunk count (wave-uniform) ----
+  int nvalid = 0;
+  {
+    int ky = 0, kx = 0;
+    for (int t = 0; t < g.KH * g.KW; ++t) {
+      nvalid += (g.a_bcast || tap_source_pixel(oy, ox, ky, kx, g.stride, g.pad, g.transposed, g.up, g.Ha, g.Wa) >= 0) ? 1 : 0;
+      if (++kx == g.KW) { kx = 0; ++ky; }
     }
   }
-  __syncthreads();
-
-  const int nvalid = s_nvalid;
-  const int cpt1 = (g.Ca + BK - 1) / BK;
-  const int n1 = nvalid * cpt1;
-  const int total = n1 + (g.A2 ? (g.C2 + BK - 1) / BK : 0);
+  const int n1 = nvalid * (g.Kp >> 5);
+  const int total = n1 + (g.A2 ? (g.Kp2 >> 5) : 0);
   const int p2 = (oy / g.up2) * g.W2w + (ox / g.up2);
   const float* Wp = g.W + (long long)p * g.w_pix_stride;
 
-  float4 ra[RA], rb[RB];
-  auto load_chunk = [&](int i) {
-    const float* abase; const float* wbase; int lda, ldw, klen; bool gn;
-    if (i < n1) {
-      const int vi = i / cpt1, kc = (i - vi * cpt1) * BK;
-      abase = g.A + (long long)s_src[vi] * g.B * g.lda + kc;
-      wbase = Wp + (long long)s_tap[vi] * g.Npad * g.Ca + kc;
-      lda = g.lda; ldw = g.Ca; klen = g.Ca - kc; gn = g.gn_part != nullptr;
-      if (gn && skq < klen) {
-        const float4 ga = *reinterpret_cast<const float4*>(g.gn_gamma + kc + skq);
-        const float4 be = *reinterpret_cast<const float4*>(g.gn_beta + kc + skq);
+  // ---- GroupNorm(1,C) statistics of the block's BM rows from the producer's partial sums: all 256 threads
+  //      read partials (256/BM threads per row, loads batched so that they overlap), reduce through LDS ----
+  float gmean[WM], grstd[WM];
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
-          const int b = m0 + sr + 32 * j;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (b < g.B) {
-            v = *reinterpret_cast<const float4*>(abase + (long long)b * lda + skq);
-            v.x = ((v.x - gmean[j]) * grstd[j]) * ga.x + be.x;
-            v.y = ((v.y - gmean[j]) * grstd[j]) * ga.y + be.y;
-            v.z = ((v.z - gmean[j]) * grstd[j]) * ga.z + be.z;
-            v.w = ((v.w - gmean[j]) * grstd[j]) * ga.w + be.w;
-          }
-          ra[j] = v;
-        }
-      } else {
+  for (int a = 0; a < WM; ++a) { gmean[a] = 0.f; grstd[a] = 1.f; }
+  if constexpr (GN) {
+    constexpr int PL = 256 / BM;
+    const int r = tid % BM, pl = tid / BM;
+    const int b = min(m0 + r, g.B - 1);
+    double s = 0.0, q = 0.0;
+    int i = pl;
+    for (; i + 3 * PL < g.gn_nparts; i += 4 * PL) {
+      const float2 v0 = g.gn_part[(long long)i * g.B + b], v1 = g.gn_part[(long long)(i + PL) * g.B + b];
+      const float2 v2 = g.gn_part[(long long)(i + 2 * PL) * g.B + b], v3 = g.gn_part[(long long)(i + 3 * PL) * g.B + b];
+      s += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+      q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+    }
+    for (; i < g.gn_nparts; i += PL) { const float2 v = g.gn_part[(long long)i * g.B + b]; s += v.x; q += v.y; }
+    double* red = reinterpret_cast<double*>(lds);            // [PL][BM][2]
+    red[(pl * BM + r) * 2] = s; red[(pl * BM + r) * 2 + 1] = q;
+    __syncthreads();
+    float2* mr = reinterpret_cast<float2*>(lds + PL * BM * 4);   // [BM] (mean, rstd), behind the doubles
+    if (tid < BM) {
+      double ss = 0.0, qq = 0.0;
 #pragma unroll
-        for (int j = 0; j < RA; ++j) {
-          const int b = m0 + sr + 32 * j;
-          ra[j] = (b < g.B && skq < klen) ? *reinterpret_cast<const float4*>(abase + (long long)b * lda + skq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
+      for (int k = 0; k < PL; ++k) { ss += red[(k * BM + tid) * 2]; qq += red[(k * BM + tid) * 2 + 1]; }
+      const double mean = ss * (double)g.gn_inv_count;
+      double var = qq * (double)g.gn_inv_count - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      mr[tid] = make_float2((float)mean, rsqrtf((float)var + 1e-5f));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < WM; ++a) { const float2 v = mr[wave_m * 32 * WM + a * 32 + fi]; gmean[a] = v.x; grstd[a] = v.y; }
+    __syncthreads();                                           // the ring reuses this LDS
+  }
+
+  // ---- per-lane DMA source offsets for source 1 (loop invariant).  Lane l of instruction q = wave + 4j writes
+  //      LDS row r = 8q + (l >> 3), physical slot l & 7, and fetches logical slot ls = (l & 7) ^ ((r >> 1) & 7),
+  //      which does not depend on j. ----
+  const int rbase = 8 * wave + (lane >> 3);
+  const int ls4 = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 4;
+  int offs1[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j)
+    offs1[j] = j < RA ? min(m0 + rbase + 32 * j, g.B - 1) * g.lda + ls4 : min(n0 + rbase + 32 * (j - RA), g.Npad - 1) * g.Kp + ls4;
+
+  ChunkWalk cw;
+  walk_init(g, cw, oy, ox);
+  auto issue_chunk = [&](int stage) {
+    float* sbase = lds + stage * STAGE_F + wave * 256;
+    if (cw.seg == 0) {
+      const float* abase = g.A + (long long)cw.q * g.B * g.lda + cw.kc;
+      const float* wbase = Wp + (long long)cw.t * g.Npad * g.Kp + cw.kc;
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void*)((j < RA ? abase : wbase) + offs1[j]), (lds_void*)(sbase + j * 1024), 16, 0, 0);
     } else {
-      const int kc = (i - n1) * BK;
-      abase = g.A2 + (long long)p2 * g.B * g.lda2 + kc;
-      wbase = g.W2 + kc;
-      lda = g.lda2; ldw = g.C2; klen = g.C2 - kc;
+      const float* abase = g.A2 + (long long)p2 * g.B * g.lda2 + cw.kc;
+      const float* wbase = g.W2 + cw.kc;
 #pragma unroll
-      for (int j = 0; j < RA; ++j) {
-        const int b = m0 + sr + 32 * j;
-        ra[j] = (b < g.B && skq < klen) ? *reinterpret_cast<const float4*>(abase + (long long)b * lda + skq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < NI; ++j) {
+        const int o2 = j < RA ? min(m0 + rbase + 32 * j, g.B - 1) * g.lda2 + ls4 : min(n0 + rbase + 32 * (j - RA), g.Npad - 1) * g.Kp2 + ls4;
+        __builtin_amdgcn_global_load_lds((glb_void*)((j < RA ? abase : wbase) + o2), (lds_void*)(sbase + j * 1024), 16, 0, 0);
       }
     }
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const int n = n0 + sr + 32 * j;
-      rb[j] = (n < g.Npad && skq < klen) ? *reinterpret_cast<const float4*>(wbase + (long long)n * ldw + skq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (GN) {
+      // source-2 chunks carry no GroupNorm; they still fetch a (unused) gamma/beta to keep the vmcnt count uniform
+      const int kg = cw.seg == 0 ? cw.kc : 0;
+      if (lane < 16)
+        __builtin_amdgcn_global_load_lds((glb_void*)((lane < 8 ? g.gn_gamma : g.gn_beta) + kg + (lane & 7) * 4),
+                                         (lds_void*)(lds + stage * STAGE_F + ROWS * 32 + wave * 64), 16, 0, 0);
     }
+    walk_advance(g, cw, oy, ox);
   };
-  auto store_chunk = [&](int buf) {
-    float* la = lds + buf * (BM + BN) * LDS_LD;
-    float* lb = la + BM * LDS_LD;
+
+  // ---- consumer side: per-lane LDS byte addresses of the fragments (loop invariant within a stage) ----
+  const unsigned lds_base = (unsigned)(unsigned long long)(lds_void*)lds;
+  unsigned fa_off[WM][4], fb_off[WN][4], gb_off[4];
 #pragma unroll
-    for (int j = 0; j < RA; ++j) *reinterpret_cast<float4*>(la + (sr + 32 * j) * LDS_LD + skq) = ra[j];
+  for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
-    for (int j = 0; j < RB; ++j) *reinterpret_cast<float4*>(lb + (sr + 32 * j) * LDS_LD + skq) = rb[j];
-  };
+    for (int a = 0; a < WM; ++a) { const int r = wave_m * 32 * WM + a * 32 + fi; fa_off[a][kk] = r * 128 + (((2 * kk + fh) ^ ((r >> 1) & 7)) * 16); }
+#pragma unroll
+    for (int b = 0; b < WN; ++b) { const int r = BM + wave_n * 32 * WN + b * 32 + fi; fb_off[b][kk] = r * 128 + (((2 * kk + fh) ^ ((r >> 1) & 7)) * 16); }
+    gb_off[kk] = ROWS * 128 + wave * 256 + kk * 32 + fh * 16;
+  }
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -185,21 +278,40 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int fi = lane & 31, fh = lane >> 5;
-  if (total > 0) { load_chunk(0); store_chunk(0); }
-  __syncthreads();
-  for (int i = 0; i < total; ++i) {
-    const int buf = i & 1;
-    if (i + 1 < total) load_chunk(i + 1);
-    const float* la = lds + buf * (BM + BN) * LDS_LD + (wave_m * 32 * WM + fi) * LDS_LD + fh * 4;
-    const float* lb = lds + buf * (BM + BN) * LDS_LD + BM * LDS_LD + (wave_n * 32 * WN + fi) * LDS_LD + fh * 4;
+  if (g.dbg) st_t1 = __builtin_amdgcn_s_memtime();
+  int issued = 0, istage = 0;
+  for (; issued < total && issued < NST - 1; ++issued) { issue_chunk(istage); istage = istage + 1 == NST ? 0 : istage + 1; }
+
+  // one k-pair (two groups of 8 k): gather the read addresses / consume the fragments
+  auto addrs = [&](unsigned sb, int kp, unsigned* ad) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 8; ++kk) {
-      float4 fa[WM], fb[WN];
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int kk = kp * 2 + h2;
 #pragma unroll
-      for (int a = 0; a < WM; ++a) fa[a] = *reinterpret_cast<const float4*>(la + a * 32 * LDS_LD + kk * 8);
+      for (int a = 0; a < WM; ++a) ad[h2 * PER + a] = sb + fa_off[a][kk];
 #pragma unroll
-      for (int b = 0; b < WN; ++b) fb[b] = *reinterpret_cast<const float4*>(lb + b * 32 * LDS_LD + kk * 8);
+      for (int b = 0; b < WN; ++b) ad[h2 * PER + WM + b] = sb + fb_off[b][kk];
+      if constexpr (GN) { ad[h2 * PER + WM + WN] = sb + gb_off[kk]; ad[h2 * PER + WM + WN + 1] = sb + gb_off[kk] + 128; }
+    }
+  };
+  auto consume = [&](const f32x4* rd, bool apply_gn) {
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+      f32x4 fa[WM], fb[WN];
+#pragma unroll
+      for (int a = 0; a < WM; ++a) fa[a] = rd[h2 * PER + a];
+#pragma unroll
+      for (int b = 0; b < WN; ++b) fb[b] = rd[h2 * PER + WM + b];
+      if constexpr (GN) {
+        if (apply_gn) {
+          const f32x4 ga = rd[h2 * PER + WM + WN], be = rd[h2 * PER + WM + WN + 1];
+#pragma unroll
+          for (int a = 0; a < WM; ++a) {
+            const f32x4 s = ga * grstd[a];
+            fa[a] = fa[a] * s + (be - s * gmean[a]);   // (x - mean) * rstd * gamma + beta; padded k have gamma = beta = 0
+          }
+        }
+      }
 #pragma unroll
       for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -210,53 +322,85 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
         }
     }
-    if (i + 1 < total) store_chunk(buf ^ 1);
-    __syncthreads();
-  }
+  };
 
-  // ---- epilogue: out = act(acc + bias + r); optional per-row partial (sum, sumsq) ----
+  int cstage = 0;
+  for (int i = 0; i < total; ++i) {
+    if (g.dbg) st_a = __builtin_amdgcn_s_memtime();
+    if (issued - (i + 1) >= NST - 2) wait_vmcnt<(NST - 2) * IA>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();            // chunk i landed for every wave; everyone is done with chunk i-1
+    if (g.dbg) { st_b = __builtin_amdgcn_s_memtime(); st_wait += st_b - st_a; }
+    if (issued < total) { issue_chunk(istage); istage = istage + 1 == NST ? 0 : istage + 1; ++issued; }
+    if (g.dbg) { st_a = __builtin_amdgcn_s_memtime(); st_issue += st_a - st_b; }
+    const unsigned sb = lds_base + (unsigned)(cstage * STAGE_F * 4);
+    cstage = cstage + 1 == NST ? 0 : cstage + 1;
+    const bool apply_gn = GN && i < n1;
+    f32x4 r0[NRD], r1[NRD]; unsigned ad[NRD];
+    addrs(sb, 0, ad); lds_issue<NRD>(r0, ad);
+    addrs(sb, 1, ad);
+    lds_wait<NRD>(r0);
+    lds_issue<NRD>(r1, ad);                   // the second k-pair's reads fly under the first pair's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    consume(r0, apply_gn);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_wait<NRD>(r1);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(r1, apply_gn);
+    if (g.dbg) { st_b = __builtin_amdgcn_s_memtime(); st_comp += st_b - st_a; }
+  }
+  if (g.dbg) st_t2 = __builtin_amdgcn_s_memtime();
+  __syncthreads();      // all DMA retired (last wait was vmcnt(0)); LDS is reused by the epilogue
+
+  // ---- epilogue: out = act(acc + bias + r) and per-row partial (sum, sumsq).  Each wave transposes its 32-row
+  //      tile through LDS so that a lane owns 16*WN CONSECUTIVE columns of one row: the residual is read and the
+  //      result written as float4, and the row statistics are lane-local sums plus one cross-half shuffle. ----
   const float* biasp = g.bias ? g.bias + (long long)p * g.bias_pix_stride : nullptr;
-  float* srow = lds;                       // [2 (wave_n)][BM][2] floats, reused after the main loop
+  float* tile = lds + wave * 32 * EP_LD;
+  float* srow = lds + 4 * 32 * EP_LD;        // [2 (wave_n)][BM][2]
   const bool want_stats = g.stat_out != nullptr;
+  const int erow = lane & 31, ehalf = lane >> 5;
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
-    float rs[16], rq[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { rs[r] = 0.f; rq[r] = 0.f; }
 #pragma unroll
     for (int b = 0; b < WN; ++b) {
       const int n = n0 + wave_n * 32 * WN + b * 32 + fi;
-      const bool ncol = n < g.nstore;
       const float bv = (biasp && n < g.Npad) ? biasp[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wave_m * 32 * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-        const int bb = m0 + ml;
-        float v = acc[a][b][r] + bv;
-        if (ncol && bb < g.B) {
-          if (g.R) v += g.R[((long long)p2 * g.B + bb) * g.ldr + n];
-          v = act_apply(g.act, v);
-          if (g.out_nchw) {
-            const int y = oy - g.crop_y, x = ox - g.crop_x;
-            if (y >= 0 && y < g.Hn && x >= 0 && x < g.Wn) g.out[(((long long)bb * g.N + n) * g.Hn + y) * g.Wn + x] = v;
-          } else {
-            g.out[((long long)p * g.B + bb) * g.ldo + n] = v;
+      for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP_LD + b * 32 + fi] = acc[a][b][r] + bv;
+    }
+    // wave-local: LDS operations of one wave complete in order, no barrier needed
+    const int bb = m0 + wave_m * 32 * WM + a * 32 + erow;
+    const int ncol0 = n0 + wave_n * 32 * WN + ehalf * 16 * WN;
+    float s = 0.f, q = 0.f;
+    if (bb < g.B) {
+      const float* rrow = g.R ? g.R + ((long long)p2 * g.B + bb) * g.ldr : nullptr;
+#pragma unroll
+      for (int c4 = 0; c4 < 4 * WN; ++c4) {
+        const int n = ncol0 + c4 * 4;
+        float4 v = *reinterpret_cast<const float4*>(tile + erow * EP_LD + ehalf * 16 * WN + c4 * 4);
+        if (!g.out_nchw) {
+          if (n < g.nstore) {
+            if (rrow) { const float4 rv = *reinterpret_cast<const float4*>(rrow + n); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+            v.x = act_apply(g.act, v.x); v.y = act_apply(g.act, v.y); v.z = act_apply(g.act, v.z); v.w = act_apply(g.act, v.w);
+            *reinterpret_cast<float4*>(g.out + ((long long)p * g.B + bb) * g.ldo + n) = v;
+            s += (v.x + v.y) + (v.z + v.w); q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
           }
-          rs[r] += v; rq[r] += v * v;
+        } else {
+          const int y = oy - g.crop_y, x = ox - g.crop_x;
+          const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < g.nstore && y >= 0 && y < g.Hn && x >= 0 && x < g.Wn) {
+              float u = vv[e];
+              if (rrow) u += rrow[n + e];
+              g.out[(((long long)bb * g.N + n + e) * g.Hn + y) * g.Wn + x] = act_apply(g.act, u);
+            }
         }
       }
     }
     if (want_stats) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = rs[r], q = rq[r];
-#pragma unroll
-        for (int o = 16; o >= 1; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-        if (fi == 0) {
-          const int ml = wave_m * 32 * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-          srow[(wave_n * BM + ml) * 2 + 0] = s; srow[(wave_n * BM + ml) * 2 + 1] = q;
-        }
-      }
+      s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
+      if (ehalf == 0) { const int ml = wave_m * 32 * WM + a * 32 + erow; srow[(wave_n * BM + ml) * 2] = s; srow[(wave_n * BM + ml) * 2 + 1] = q; }
     }
   }
   if (want_stats) {
@@ -265,6 +409,11 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
       const float s = srow[tid * 2] + srow[(BM + tid) * 2], q = srow[tid * 2 + 1] + srow[(BM + tid) * 2 + 1];
       g.stat_out[((long long)p * g.ntiles + nt) * g.B + m0 + tid] = make_float2(s, q);
     }
+  }
+  if (g.dbg && tid == 0 && (int)blockIdx.x == (int)(gridDim.x / 2)) {
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    g.dbg[0] = st_t1 - st_t0; g.dbg[1] = st_t2 - st_t1; g.dbg[2] = t3 - st_t2; g.dbg[3] = st_wait; g.dbg[4] = st_issue; g.dbg[5] = st_comp;
+    g.dbg[6] = (unsigned long long)total; g.dbg[7] = gridDim.x;
   }
 }
 
@@ -493,6 +642,8 @@ __global__ void bilinear_kernel(const BilArgs o) {
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
+unsigned long long* g_gemm_dbg = nullptr;   // set by sbm_debug_gemm_stamps (diagnostics only)
+
 static const char* launch_gemm(const GemmOp& o, const float* prm, float* ws, const float* ext_in, float* ext_out, hipStream_t st) {
   GemmArgs g{};
   g.A = (o.a_ext ? ext_in : ws) + o.a.off;
@@ -506,23 +657,32 @@ static const char* launch_gemm(const GemmOp& o, const float* prm, float* ws, con
   g.stat_out = o.stat_off >= 0 ? reinterpret_cast<float2*>(ws + o.stat_off) : nullptr;
   g.w_pix_stride = o.w_pix_stride; g.bias_pix_stride = o.bias_pix_stride;
   g.B = o.B; g.Hout = o.Hout; g.Wout = o.Wout;
-  g.lda = o.a.ld; g.Ca = o.a.C; g.Ha = o.a.H; g.Wa = o.a.W; g.up = o.up; g.KH = o.KH; g.KW = o.KW; g.stride = o.stride; g.pad = o.pad;
+  g.lda = o.a.ld; g.Kp = o.Kp; g.Ha = o.a.H; g.Wa = o.a.W; g.up = o.up; g.KH = o.KH; g.KW = o.KW; g.stride = o.stride; g.pad = o.pad;
   g.transposed = o.transposed; g.a_bcast = o.a_bcast;
   g.gn_nparts = o.gn_nparts; g.gn_inv_count = o.gn_inv_count;
-  g.lda2 = o.a2.ld; g.C2 = o.a2.C; g.up2 = o.up2; g.W2w = o.has2 ? o.a2.W : (o.has_res ? o.r.W : 1);
-  g.ldr = o.r.ld; g.Wr = o.r.W;
+  g.lda2 = o.a2.ld; g.Kp2 = o.Kp2; g.up2 = o.up2; g.W2w = o.has2 ? o.a2.W : (o.has_res ? o.r.W : 1);
+  g.ldr = o.r.ld;
   g.act = o.act; g.ldo = o.out.ld; g.nstore = o.out_nchw ? o.N : o.out.C; g.Npad = o.Npad; g.out_nchw = o.out_nchw; g.N = o.N;
   g.crop_y = o.crop_y; g.crop_x = o.crop_x; g.Hn = o.Hn; g.Wn = o.Wn;
   g.mtiles = ceil_div(o.B, o.BM); g.ntiles = ceil_div(g.nstore, o.BN);
-  if (o.KH * o.KW > 64) return "seg_gemm: more than 64 taps";
-  if ((o.a.C & 3) || (o.a.ld & 3) || (o.has2 && ((o.a2.C & 3) || (o.a2.ld & 3)))) return "seg_gemm: channel counts / pitches must be multiples of 4";
+  g.dbg = g_gemm_dbg;
+  if ((o.a.ld & 3) || (o.has2 && (o.a2.ld & 3))) return "seg_gemm: row pitches must be multiples of 4 floats";
+  if (o.Kp <= 0 || (o.Kp & 31) || (o.has2 && (o.Kp2 <= 0 || (o.Kp2 & 31)))) return "seg_gemm: weight K stride must be a positive multiple of 32";
+  if (o.a_ext && o.a.C != o.Kp) return "seg_gemm: an external input matrix must have a multiple of 32 columns";
+  if ((long long)o.B * (o.a.ld > o.a2.ld ? o.a.ld : o.a2.ld) >= (1LL << 30) || (long long)o.Npad * (o.Kp > o.Kp2 ? o.Kp : o.Kp2) >= (1LL << 30))
+    return "seg_gemm: operand plane too large for 32-bit lane offsets";
   const long long blocks = (long long)o.Hout * o.Wout * g.mtiles * g.ntiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return "seg_gemm: bad grid";
   dim3 grid((unsigned)blocks), block(256);
-  if (o.BM == 64 && o.BN == 64) hipLaunchKernelGGL((seg_gemm<64, 64>), grid, block, 0, st, g);
-  else if (o.BM == 128 && o.BN == 64) hipLaunchKernelGGL((seg_gemm<128, 64>), grid, block, 0, st, g);
-  else if (o.BM == 128 && o.BN == 128) hipLaunchKernelGGL((seg_gemm<128, 128>), grid, block, 0, st, g);
+  const bool gn = o.gn != 0;
+#define SBM_LAUNCH(BM_, BN_, NST_) \
+  do { if (gn) hipLaunchKernelGGL((seg_gemm<BM_, BN_, NST_, true>), grid, block, 0, st, g); \
+       else hipLaunchKernelGGL((seg_gemm<BM_, BN_, NST_, false>), grid, block, 0, st, g); } while (0)
+  if (o.BM == 64 && o.BN == 64) SBM_LAUNCH(64, 64, 4);
+  else if (o.BM == 128 && o.BN == 64) SBM_LAUNCH(128, 64, 4);
+  else if (o.BM == 128 && o.BN == 128) SBM_LAUNCH(128, 128, 3);
   else return "seg_gemm: unsupported tile";
+#undef SBM_LAUNCH
   return nullptr;
 }
 

@@ -194,7 +194,9 @@ class Builder {
 
   // ---- workspace allocator: first-fit free list, blocks rounded to 64 floats (256 B) ----
   int64_t ws_alloc(int64_t n) {
-    n = (n + 63) / 64 * 64;
+    // +32 floats of slack: the GEMM kernel reads whole 32-float K chunks, so the last row of a tensor whose
+    // channel count is not a multiple of 32 is read up to 28 floats past its end (times zero weights)
+    n = (n + 32 + 63) / 64 * 64;
     for (size_t i = 0; i < free_list.size(); ++i) {
       if (free_list[i].n >= n) {
         int64_t off = free_list[i].off;
@@ -305,19 +307,21 @@ class Builder {
     g.N = s.cout;
     const int nstore = s.out_nchw ? s.cout : pad8(s.cout);
     g.Npad = round_up(nstore, 32);
-    g.w_off = add_params(pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, s.a.C, g.Npad, s.transposed, s.out_scale));
+    g.Kp = round_up(s.a.C, 32);
+    g.w_off = add_params(pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, g.Kp, g.Npad, s.transposed, s.out_scale));
     std::vector<double> bias(g.Npad, 0.0);
     bool any_bias = false;
     if (s.bias) { for (int n = 0; n < s.cout; ++n) bias[n] += (s.out_scale ? (*s.out_scale)[n] : 1.0) * s.bias[n]; any_bias = true; }
     if (s.out_shift) { for (int n = 0; n < s.cout; ++n) bias[n] += (*s.out_shift)[n]; any_bias = true; }
     if (s.gn) {
       g.gn = 1; g.gn_part_off = s.gn_part; g.gn_nparts = s.gn_nparts; g.gn_inv_count = s.gn_inv;
-      g.gn_gamma_off = add_params(pack_vec(s.gamma, s.cin_true, &s.cm, s.a.C));
-      g.gn_beta_off = add_params(pack_vec(s.beta, s.cin_true, &s.cm, s.a.C));
+      g.gn_gamma_off = add_params(pack_vec(s.gamma, s.cin_true, &s.cm, g.Kp));
+      g.gn_beta_off = add_params(pack_vec(s.beta, s.cin_true, &s.cm, g.Kp));
     }
     if (s.has2) {
       g.has2 = 1; g.a2 = s.a2; g.up2 = s.up2;
-      g.w2_off = add_params(pack_conv(s.w2, s.cout, s.cin2, 1, 1, s.cm2, s.a2.C, g.Npad, false, nullptr));
+      g.Kp2 = round_up(s.a2.C, 32);
+      g.w2_off = add_params(pack_conv(s.w2, s.cout, s.cin2, 1, 1, s.cm2, g.Kp2, g.Npad, false, nullptr));
       if (s.bias2) { for (int n = 0; n < s.cout; ++n) bias[n] += s.bias2[n]; any_bias = true; }
     }
     if (any_bias) { std::vector<float> bf(bias.begin(), bias.end()); g.bias_off = add_params(bf); }
@@ -351,7 +355,8 @@ class Builder {
     double dense_taps = s.transposed ? (double)s.a.H * s.a.W * s.kh * s.kw : (double)P * s.kh * s.kw;
     plan->flops_dense += 2.0 * B * s.cout * (dense_taps * s.cin_true + (s.has2 ? (double)P * s.cin2 : 0.0));
     plan->flops_dense_gemm += 2.0 * B * s.cout * (dense_taps * s.cin_true + (s.has2 ? (double)P * s.cin2 : 0.0));
-    plan->flops_exec += 2.0 * B * g.Npad * (taps_valid * s.a.C + (s.has2 ? (double)P * s.a2.C : 0.0));
+    op.flops = 2.0 * B * g.Npad * (taps_valid * s.a.C + (s.has2 ? (double)P * s.a2.C : 0.0));
+    plan->flops_exec += op.flops;
     return res;
   }
 };
@@ -515,19 +520,21 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       Op& op = b.push(OP_GEMM, "convnext mlp.1 (all blocks)");
       GemmOp& g = op.g; g.B = B; g.a = e2; g.N = cond_ld; g.Npad = round_up(cond_ld, 32); g.out = cond_all;
       Builder::choose_tile(B, 1, cond_ld, &g.BM, &g.BN);
-      plan->flops_exec += 2.0 * B * g.Npad * d.td;
+      op.flops = 2.0 * B * g.Npad * d.td;
+      plan->flops_exec += op.flops;
       b.free_act(e2);   // ops run in stream order: e2 is dead once the GEMM above has executed
     }
     const size_t cond_op_index = plan->ops.size() - 1;
     std::vector<float> cond_w, cond_b;
-    if (d.td) { cond_w.assign((size_t)round_up(cond_ld, 32) * d.td, 0.f); cond_b.assign(round_up(cond_ld, 32), 0.f); }
+    const int td_p = round_up(d.td, 32);
+    if (d.td) { cond_w.assign((size_t)round_up(cond_ld, 32) * td_p, 0.f); cond_b.assign(round_up(cond_ld, 32), 0.f); }
     auto add_cond = [&](const std::string& pre, int cin, const ChanMap& cm) {
       if (!d.td) return;
       const float* w = b.T(pre + "mlp.1.weight", (int64_t)cin * d.td);
       const float* bb = b.T(pre + "mlp.1.bias", cin);
       const int col = cond_col.at(pre);
       for (int c = 0; c < cin; ++c) {
-        std::memcpy(&cond_w[(size_t)(col + cm.idx[c]) * d.td], &w[(size_t)c * d.td], sizeof(float) * d.td);
+        std::memcpy(&cond_w[(size_t)(col + cm.idx[c]) * td_p], &w[(size_t)c * d.td], sizeof(float) * d.td);
         cond_b[col + cm.idx[c]] = bb[c];
       }
       plan->flops_dense += 2.0 * B * cin * d.td; plan->flops_dense_gemm += 2.0 * B * cin * d.td;
@@ -627,7 +634,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
     // patch the concatenated mlp weights
     if (d.td) {
       GemmOp& g = plan->ops[cond_op_index].g;
-      g.w_off = b.add_params(cond_w);
+      g.w_off = b.add_params(cond_w); g.Kp = td_p;
       g.bias_off = b.add_params(cond_b);
     }
     return true;
@@ -695,12 +702,13 @@ bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const
       g.a_ext = 1; g.a_bcast = 1; g.a.C = cfg.size_z; g.a.ld = z_ld; g.a.H = g.a.W = 1; g.a.off = 0;
       g.N = clast; g.Npad = round_up(pad8(clast), 32);
       const float* w = b.T("z_lin.weight", (int64_t)P0 * clast * cfg.size_z); const float* bi = b.T("z_lin.bias", (int64_t)P0 * clast);
-      std::vector<float> wp((size_t)P0 * g.Npad * cfg.size_z, 0.f), bp((size_t)P0 * g.Npad, 0.f);
+      g.Kp = round_up(cfg.size_z, 32);
+      std::vector<float> wp((size_t)P0 * g.Npad * g.Kp, 0.f), bp((size_t)P0 * g.Npad, 0.f);
       for (int p = 0; p < P0; ++p) for (int c = 0; c < clast; ++c) {
-        std::memcpy(&wp[((size_t)p * g.Npad + c) * cfg.size_z], &w[((size_t)c * P0 + p) * cfg.size_z], sizeof(float) * cfg.size_z);
+        std::memcpy(&wp[((size_t)p * g.Npad + c) * g.Kp], &w[((size_t)c * P0 + p) * cfg.size_z], sizeof(float) * cfg.size_z);
         bp[(size_t)p * g.Npad + c] = bi[(size_t)c * P0 + p];
       }
-      g.w_off = b.add_params(wp); g.w_pix_stride = (int64_t)g.Npad * cfg.size_z;
+      g.w_off = b.add_params(wp); g.w_pix_stride = (int64_t)g.Npad * g.Kp;
       g.bias_off = b.add_params(bp); g.bias_pix_stride = g.Npad;
       g.act = ACT_RELU; g.out = h;
       Builder::choose_tile(B, P0, pad8(clast), &g.BM, &g.BN);

@@ -51,7 +51,7 @@ struct GemmOp {
   int up = 1;             // nearest-neighbour upsample folded into the read (source pixel = q / up)
   int KH = 1, KW = 1, stride = 1, pad = 0, transposed = 0;
   int a_bcast = 0;        // 1: source is a single-pixel tensor read by every output pixel
-  int64_t w_off = 0;      // params: [tap][Npad][a.C]
+  int64_t w_off = 0;      // params: [tap][Npad][Kp]
   int64_t w_pix_stride = 0;  // params: extra offset per output pixel (z_lin), else 0
   // GroupNorm(1,C) applied on load to source 1
   int gn = 0;
@@ -64,7 +64,7 @@ struct GemmOp {
   int has2 = 0;
   View a2;
   int up2 = 1;            // nearest upsample folded into the reads of source 2 and of the residual r
-  int64_t w2_off = 0;     // params: [Npad][a2.C]
+  int64_t w2_off = 0;     // params: [Npad][Kp2]
   // epilogue: out = act(acc + bias + r)
   int64_t bias_off = -1;  // params [Npad]
   int64_t bias_pix_stride = 0;  // params: extra bias offset per output pixel (z_lin), else 0
@@ -78,6 +78,8 @@ struct GemmOp {
   int crop_y = 0, crop_x = 0, Hn = 0, Wn = 0;  // out_nchw: crop of the padded grid
   int64_t stat_off = -1;  // workspace: float2 [P_out * ntiles][B] partial (sum, sumsq) of the stored rows
   int BM = 64, BN = 64;   // tile configuration (fixes ntiles = ceil(out.C / BN))
+  int Kp = 0, Kp2 = 0;    // K stride of the weight rows of source 1 / 2: a.C / a2.C rounded up to 32, zero
+                          // filled, so that the kernel needs no K-tail predicate (gamma/beta are padded alike)
 };
 
 struct DwOp {
@@ -117,6 +119,7 @@ struct GnFinalOp { int B = 0; int64_t part_off = 0; int nparts = 0; int64_t out_
 struct Op {
   int kind = 0;
   std::string name;       // reference layer this op implements (for profiles and error messages)
+  double flops = 0;       // 2*MAC this op issues (padding taps skipped, channel padding included)
   GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf;
 };
 
