@@ -24,6 +24,8 @@ struct sbm_model {
   Plan plan;
   float* d_params = nullptr;
   float* d_ws = nullptr;
+  GemmCold* d_cold = nullptr;    // one per op (only the GEMM entries are meaningful)
+  DevPlan dp;
   // sampler scratch (score nets only)
   float* d_score = nullptr;
   float* d_norms = nullptr;
@@ -81,6 +83,7 @@ void sbm_model_destroy(sbm_model* m) {
   if (m->own) (void)hipStreamSynchronize(m->own);
   if (m->d_params) (void)hipFree(m->d_params);
   if (m->d_ws) (void)hipFree(m->d_ws);
+  if (m->d_cold) (void)hipFree(m->d_cold);
   if (m->d_score) (void)hipFree(m->d_score);
   if (m->d_norms) (void)hipFree(m->d_norms);
   if (m->d_counter) (void)hipFree(m->d_counter);
@@ -114,6 +117,19 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   if ((e = hipMemcpy(m->d_params, m->plan.params.data(), pbytes, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(params)", e); }
   if ((e = hipMemset(m->d_ws, 0, wbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemset(workspace)", e); }
   std::vector<float>().swap(m->plan.params);          // host copy no longer needed
+  {
+    // resolve every GEMM op into kernel arguments once; the cold halves live in device memory
+    const size_t nops = m->plan.ops.size();
+    std::vector<GemmCold> cold(nops);
+    if ((e = hipMalloc(&m->d_cold, sizeof(GemmCold) * (nops ? nops : 1))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(cold args)", e); }
+    m->dp.plan = &m->plan; m->dp.prm = m->d_params; m->dp.ws = m->d_ws; m->dp.hot.resize(nops);
+    for (size_t i = 0; i < nops; ++i) {
+      if (m->plan.ops[i].kind != OP_GEMM) { std::memset(&cold[i], 0, sizeof(GemmCold)); continue; }
+      const char* ge = make_gemm_args(m->plan, m->plan.ops[i].g, m->d_params, m->d_ws, m->d_cold + i, &m->dp.hot[i], &cold[i]);
+      if (ge) { std::string msg = std::string(ge) + " (" + m->plan.ops[i].name + ")"; sbm_model_destroy(m); return fail("sbm_model_create: " + msg); }
+    }
+    if ((e = hipMemcpy(m->d_cold, cold.data(), sizeof(GemmCold) * nops, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(cold args)", e); }
+  }
   if (kind == SBM_UNET) {
     const size_t sbytes = (size_t)batch * m->plan.out_C * m->plan.out_H * m->plan.out_W * sizeof(float);
     if ((e = hipMalloc(&m->d_score, sbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(score)", e); }
@@ -140,7 +156,7 @@ int sbm_model_info(const sbm_model* m, double* info) {
 int sbm_model_forward(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, void* stream) {
   if (!m || !in_dev || !out_dev) return fail("sbm_model_forward: bad arguments");
   if (m->plan.needs_time && !t_dev) return fail("sbm_model_forward: this score net needs a time vector");
-  const char* e = run_plan(m->plan, m->d_params, m->d_ws, in_dev, t_dev, out_dev, (hipStream_t)stream);
+  const char* e = run_plan(m->dp, in_dev, t_dev, out_dev, (hipStream_t)stream);
   return e ? fail(std::string("sbm_model_forward: ") + e) : 0;
 }
 
@@ -150,7 +166,7 @@ int sbm_debug_forward_partial(sbm_model* m, const float* in_dev, const float* t_
   hipStream_t st = (hipStream_t)stream;
   if (m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
   for (int i = 0; i < n_ops && i < (int)m->plan.ops.size(); ++i) {
-    const char* e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, st);
+    const char* e = launch_op(m->dp, (int)i, in_dev, out_dev, st);
     if (e) return fail(e);
   }
   HIPCHK(hipStreamSynchronize(st));
@@ -161,7 +177,7 @@ int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_de
   hipStream_t st = (hipStream_t)stream;
   if (first == 0 && m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
   for (int i = first; i < last && i < (int)m->plan.ops.size(); ++i) {
-    const char* e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, st);
+    const char* e = launch_op(m->dp, (int)i, in_dev, out_dev, st);
     if (e) return fail(e);
   }
   HIPCHK(hipStreamSynchronize(st));
@@ -172,13 +188,13 @@ int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_de
 int sbm_debug_gemm_stamps(sbm_model* m, const float* in_dev, float* out_dev, int i, unsigned long long* stamps_host) {
   if (!m || i < 0 || i >= (int)m->plan.ops.size() || m->plan.ops[i].kind != OP_GEMM) return fail("sbm_debug_gemm_stamps: not a GEMM op");
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc(&d, 64)); HIPCHK(hipMemset(d, 0, 64));
+  HIPCHK(hipMalloc(&d, 128)); HIPCHK(hipMemset(d, 0, 128));
   g_gemm_dbg = d;
-  const char* e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, m->own);
+  const char* e = launch_op(m->dp, i, in_dev, out_dev, m->own);
   g_gemm_dbg = nullptr;
   if (e) return fail(e);
   HIPCHK(hipStreamSynchronize(m->own));
-  HIPCHK(hipMemcpy(stamps_host, d, 64, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(stamps_host, d, 128, hipMemcpyDeviceToHost));
   (void)hipFree(d);
   return 0;
 }
@@ -200,7 +216,7 @@ int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap) {
 int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, double* ms_per_op, double* flops_per_op, int n_ops) {
   if (!m || !in_dev || !out_dev || reps <= 0 || !ms_per_op) return fail("sbm_debug_profile_ops: bad arguments");
   hipStream_t st = m->own;
-  const char* e = run_plan(m->plan, m->d_params, m->d_ws, in_dev, t_dev, out_dev, st);
+  const char* e = run_plan(m->dp, in_dev, t_dev, out_dev, st);
   if (e) return fail(e);
   HIPCHK(hipStreamSynchronize(st));
   const size_t nops = m->plan.ops.size();
@@ -210,7 +226,7 @@ int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev,
   for (int r = 0; r < reps; ++r) {
     HIPCHK(hipEventRecord(ev[0], st));
     for (size_t i = 0; i < nops; ++i) {
-      e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, st);
+      e = launch_op(m->dp, (int)i, in_dev, out_dev, st);
       if (e) return fail(e);
       HIPCHK(hipEventRecord(ev[i + 1], st));
     }
@@ -225,7 +241,7 @@ int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, flo
   if (!m || !in_dev || !out_dev || reps <= 0 || !ms_by_kind || !launches_by_kind) return fail("sbm_model_profile: bad arguments");
   for (int k = 0; k < n_kinds; ++k) { ms_by_kind[k] = 0; launches_by_kind[k] = 0; }
   hipStream_t st = m->own;
-  const char* e = run_plan(m->plan, m->d_params, m->d_ws, in_dev, t_dev, out_dev, st);       // warm-up
+  const char* e = run_plan(m->dp, in_dev, t_dev, out_dev, st);       // warm-up
   if (e) return fail(e);
   HIPCHK(hipStreamSynchronize(st));
   const size_t nops = m->plan.ops.size();
@@ -235,7 +251,7 @@ int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, flo
     if (m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipEventRecord(ev[0], st));
     for (size_t i = 0; i < nops; ++i) {
-      e = launch_op(m->plan, m->plan.ops[i], m->d_params, m->d_ws, in_dev, out_dev, st);
+      e = launch_op(m->dp, (int)i, in_dev, out_dev, st);
       if (e) return fail(e);
       HIPCHK(hipEventRecord(ev[i + 1], st));
     }
@@ -300,7 +316,7 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
   a.noise_step_stride = (long long)dps * B * CHW;
   auto score_eval = [&]() -> const char* {
     launch_fill_time(tbuf, timesteps, m->d_counter, B, st);
-    return run_plan(P, m->d_params, m->d_ws, x, tbuf, m->d_score, st);
+    return run_plan(m->dp, x, tbuf, m->d_score, st);
   };
   auto corrector = [&](int first_draw) -> const char* {
     for (int i = 0; i < c.n_steps; ++i) {

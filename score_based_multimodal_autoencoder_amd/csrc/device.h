@@ -3,17 +3,46 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "plan.h"
 
 namespace sbm {
 
-// Enqueue every op of `plan` on `st`.  Returns nullptr or a static error string.  No allocation, no
-// synchronisation: safe to capture into a hipGraph.
-const char* run_plan(const Plan& plan, const float* params_dev, float* ws_dev, const float* ext_in, const float* t_dev,
-                     float* ext_out, hipStream_t st);
+// seg_gemm kernel arguments: a small by-value part used inside the K loop, and the rest in device memory.
+struct GemmCold {
+  const float* bias;          // [Npad] (+ p * bias_pix_stride) or null
+  const float* R;             // residual view origin or null
+  const float2* gn_part;      // GroupNorm partial sums of source 1 [gn_nparts][B]
+  const float* gn_s; const float* gn_b1;   // folded-GroupNorm tables [P_out][Npad] (plan.h)
+  float2* stat_out;           // partial (sum, sumsq) of the stored rows [P * ntiles][B] or null
+  long long bias_pix_stride;
+  int gn_nparts; float gn_inv_count;
+  int ldr, act, ldo, nstore, out_nchw, N, crop_y, crop_x, Hn, Wn, Wout;
+};
+struct GemmHot {
+  const float* A; const float* A2;      // source 1 / 2 view origins
+  const float* W; const float* W2;      // [tap][Npad][Kp] / [Npad][Kp2]
+  const int4* desc; const int4* hdr;    // host-built chunk tables (plan.h ChunkDesc / PixHdr)
+  const GemmCold* cold;
+  float* out;                           // PBC view origin, or the external NCHW output
+  int B, lda, lda2, Kp, Kp2, Npad, mtiles, ntiles;
+  unsigned long long* dbg;              // diagnostic cycle stamps (null in production)
+};
 
-const char* launch_op(const Plan& plan, const Op& op, const float* params_dev, float* ws_dev, const float* ext_in, float* ext_out,
-                      hipStream_t st);
+// A plan resolved against its device arenas.
+struct DevPlan {
+  const Plan* plan = nullptr;
+  const float* prm = nullptr;   // device params arena
+  float* ws = nullptr;          // device workspace arena
+  std::vector<GemmHot> hot;     // per op (valid for OP_GEMM)
+};
+const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, float* ws, const GemmCold* cold_dev, GemmHot* hot, GemmCold* cold);
+
+// Enqueue every op of the plan on `st`.  Returns nullptr or a static error string.  No allocation, no
+// synchronisation: safe to capture into a hipGraph.
+const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st);
+const char* launch_op(const DevPlan& dp, int op_index, const float* ext_in, float* ext_out, hipStream_t st);
 
 extern unsigned long long* g_gemm_dbg;
 

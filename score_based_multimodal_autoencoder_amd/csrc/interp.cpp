@@ -41,50 +41,49 @@ static void gn_mean_rstd(const float* ws, int64_t part_off, int nparts, int B, i
 }
 
 static void run_gemm(const GemmOp& g, const float* prm, float* ws, const float* ext_in, float* ext_out) {
+  // Walks the SAME host-built chunk tables the HIP kernel reads (hdr/desc), so the tables are tested on the CPU.
   const int B = g.B, P = g.Hout * g.Wout;
   const int nstore = g.out_nchw ? g.N : g.out.C;
   const int ntiles = ceil_div(nstore, g.BN);
-  const float* Abase = g.a_ext ? ext_in : ws;
+  const float* A1 = (g.a_ext ? ext_in : ws) + g.a.off;
+  const float* A2 = g.has2 ? ws + g.a2.off : nullptr;
+  const int* hdr = reinterpret_cast<const int*>(prm + g.hdr_off);
+  const int* desc = reinterpret_cast<const int*>(prm + g.desc_off);
   std::vector<float> mean(B, 0.f), rstd(B, 1.f);
   if (g.gn) for (int b = 0; b < B; ++b) gn_mean_rstd(ws, g.gn_part_off, g.gn_nparts, B, b, g.gn_inv_count, &mean[b], &rstd[b]);
-  std::vector<float> arow((size_t)g.KH * g.KW * g.a.C + (g.has2 ? g.a2.C : 0));
-  std::vector<int> taps; std::vector<int> srcs;
+  std::vector<float> acc(nstore), acc2(nstore);
   for (int p = 0; p < P; ++p) {
     const int oy = p / g.Wout, ox = p % g.Wout;
-    taps.clear(); srcs.clear();
-    for (int ky = 0; ky < g.KH; ++ky) for (int kx = 0; kx < g.KW; ++kx) {
-      int q = g.a_bcast ? 0 : tap_source_pixel(oy, ox, ky, kx, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W);
-      if (q >= 0) { taps.push_back(ky * g.KW + kx); srcs.push_back(q); }
-    }
-    const int p2 = (oy / g.up2) * (g.has2 ? g.a2.W : (g.has_res ? g.r.W : 1)) + (ox / g.up2);
-    const float* W = prm + g.w_off + (int64_t)p * g.w_pix_stride;
+    const int first = hdr[4 * p], total = hdr[4 * p + 1], p2 = hdr[4 * p + 3];
     const float* bias = g.bias_off >= 0 ? prm + g.bias_off + (int64_t)p * g.bias_pix_stride : nullptr;
     for (int b = 0; b < B; ++b) {
-      // gather the (GroupNorm-transformed) A row for this output pixel
-      for (size_t t = 0; t < taps.size(); ++t) {
-        const float* a = Abase + g.a.off + ((int64_t)srcs[t] * B + b) * g.a.ld;
-        float* dst = &arow[t * g.a.C];
-        if (g.gn) {
-          const float* ga = prm + g.gn_gamma_off; const float* be = prm + g.gn_beta_off;
-          for (int k = 0; k < g.a.C; ++k) dst[k] = ((a[k] - mean[b]) * rstd[b]) * ga[k] + be[k];
-        } else {
-          std::memcpy(dst, a, sizeof(float) * g.a.C);
+      std::fill(acc.begin(), acc.end(), 0.f); std::fill(acc2.begin(), acc2.end(), 0.f);
+      for (int c = 0; c < total; ++c) {
+        const int* d = desc + 4 * (first + c);
+        const bool src2 = d[3] & 1;
+        const float* arow = (src2 ? A2 : A1) + d[0] + (int64_t)b * (src2 ? g.a2.ld : g.a.ld);
+        const float* wbase = prm + (src2 ? g.w2_off : g.w_off) + d[1];
+        const int ldw = src2 ? g.Kp2 : g.Kp;
+        // the kernel multiplies the whole 32-wide chunk; beyond the true channel count the weights are zero
+        const int kc = src2 ? d[1] : (d[1] % g.Kp);
+        const int klen = std::min(32, (src2 ? g.a2.C : g.a.C) - kc);
+        std::vector<float>& dst = src2 ? acc2 : acc;
+        for (int n = 0; n < nstore; ++n) {
+          const float* w = wbase + (int64_t)n * ldw;
+          float s = dst[n];
+          for (int k = 0; k < klen; ++k) s = std::fmaf(arow[k], w[k], s);
+          dst[n] = s;
         }
       }
-      const float* a2 = g.has2 ? ws + g.a2.off + ((int64_t)p2 * B + b) * g.a2.ld : nullptr;
+      // folded GroupNorm (plan.h): source 1 is scaled by rstd and corrected with the host tables S / B1
+      for (int n = 0; n < nstore; ++n) {
+        float v = acc[n];
+        if (g.gn) v = rstd[b] * v + (prm[g.gn_b1_off + (int64_t)p * g.Npad + n] - (mean[b] * rstd[b]) * prm[g.gn_s_off + (int64_t)p * g.Npad + n]);
+        acc[n] = v + acc2[n];
+      }
       std::vector<double> tsum(ntiles, 0.0), tsq(ntiles, 0.0);
       for (int n = 0; n < nstore; ++n) {
-        float acc = 0.f;
-        for (size_t t = 0; t < taps.size(); ++t) {
-          const float* w = W + ((int64_t)taps[t] * g.Npad + n) * g.Kp;
-          const float* a = &arow[t * g.a.C];
-          for (int k = 0; k < g.a.C; ++k) acc = std::fmaf(a[k], w[k], acc);
-        }
-        if (g.has2) {
-          const float* w2 = prm + g.w2_off + (int64_t)n * g.Kp2;
-          for (int k = 0; k < g.a2.C; ++k) acc = std::fmaf(a2[k], w2[k], acc);
-        }
-        float v = acc;
+        float v = acc[n];
         if (bias) v += bias[n];
         if (g.has_res) v += ws[g.r.off + ((int64_t)p2 * B + b) * g.r.ld + n];
         v = act_apply(g.act, v);

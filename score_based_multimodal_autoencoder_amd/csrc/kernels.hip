@@ -32,34 +32,22 @@ DEVINL float act_apply(int act, float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// seg_gemm  (LDS-DMA ring)
+// seg_gemm  (LDS-DMA ring, host-built chunk tables)
 // ------------------------------------------------------------------------------------------------
-struct GemmArgs {
-  const float* A;      // source 1 base (already offset to the view origin)
-  const float* W;      // [tap][Npad][Kp]
-  const float* A2;     // source 2 base or null
-  const float* W2;     // [Npad][Kp2]
-  const float* bias;   // [Npad] or null
-  const float* R;      // residual base or null
-  float* out;          // PBC view origin, or NCHW base
-  const float2* gn_part; const float* gn_gamma; const float* gn_beta;
-  float2* stat_out;
-  long long w_pix_stride, bias_pix_stride;
-  int B, Hout, Wout;
-  int lda, Kp, Ha, Wa, up, KH, KW, stride, pad, transposed, a_bcast;
-  int gn_nparts; float gn_inv_count;
-  int lda2, Kp2, W2w, up2;
-  int ldr;
-  int act, ldo, nstore, Npad, out_nchw, N, crop_y, crop_x, Hn, Wn;
-  int mtiles, ntiles;
-  unsigned long long* dbg;   // diagnostic build only: cycle stamps of one block's wave 0 (null in production)
-};
-
 constexpr int BK = 32;        // K chunk = one 128-byte LDS row per operand row
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) i32x4 const_i32x4;   // constant address space: uniform loads become s_load
+
+// Wave-uniform 16-byte table read through the scalar cache (SMEM counts on lgkmcnt, never on vmcnt, so it cannot
+// make hipcc drain the LDS-DMA ring the way an ordinary global_load would).
+DEVINL int4 scalar_load16(const int4* p) {
+  const i32x4 v = *(const_i32x4*)(unsigned long long)p;
+  return make_int4(v.x, v.y, v.z, v.w);
+}
 
 // Fragment reads are inline asm: hipcc must not see an LDS read while LDS-DMA is in flight, or it drains the
 // whole ring (s_waitcnt vmcnt(0)) in front of it.  `lds_issue` starts N ds_read_b128, `lds_wait` is the
@@ -103,171 +91,157 @@ template <> DEVINL void lds_wait<12>(f32x4* o) {
 }
 template <int N> DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// Walk over the K chunks of one output pixel: valid taps of source 1 (Kp / 32 chunks each), then source 2.
-// All state is wave-uniform; no integer division anywhere.
-struct ChunkWalk {
-  int seg;        // 0: source 1, 1: source 2, 2: exhausted
-  int t, ky, kx;  // current tap of source 1
-  int q;          // its source pixel
-  int kc;         // K offset inside the current tap / inside source 2
-};
-
-DEVINL void walk_next_tap(const GemmArgs& g, ChunkWalk& w, int oy, int ox) {
-  const int ntaps = g.KH * g.KW;
-  for (;;) {
-    ++w.t; ++w.kx;
-    if (w.kx == g.KW) { w.kx = 0; ++w.ky; }
-    if (w.t >= ntaps) { w.seg = g.A2 ? 1 : 2; w.kc = 0; return; }
-    const int q = g.a_bcast ? 0 : tap_source_pixel(oy, ox, w.ky, w.kx, g.stride, g.pad, g.transposed, g.up, g.Ha, g.Wa);
-    if (q >= 0) { w.q = q; w.kc = 0; return; }
-  }
-}
-DEVINL void walk_init(const GemmArgs& g, ChunkWalk& w, int oy, int ox) {
-  w.seg = 0; w.t = -1; w.ky = 0; w.kx = -1; w.q = 0; w.kc = 0;
-  walk_next_tap(g, w, oy, ox);
-}
-DEVINL void walk_advance(const GemmArgs& g, ChunkWalk& w, int oy, int ox) {
-  w.kc += BK;
-  if (w.seg == 0) { if (w.kc >= g.Kp) walk_next_tap(g, w, oy, ox); }
-  else if (w.kc >= g.Kp2) w.seg = 2;
-}
-
 // One workgroup = 4 waves (2 x 2) computing out[p][m0:m0+BM][n0:n0+BN].
 //
-// LDS ring of NST stages; a stage holds one K chunk: BM A rows + BN B rows of 128 bytes, filled by LDS-DMA
-// (global_load_lds_dwordx4: each wave-instruction writes 1 KiB = 8 rows).  Rows are unpadded -- the DMA write is
-// lane-linear -- so the 16-byte slots of a row are XOR-swizzled by (row >> 1) & 7 on the SOURCE address and on the
-// fragment read, which makes ds_read_b128 conflict-free.  With GroupNorm a stage also holds one private 256-byte
-// {gamma, beta} copy per wave, and the normalisation is applied to the A fragments in registers.
+// K is walked in 32-wide chunks listed by the host (GemmHot::desc): valid taps of source 1, then source 2; zero
+// padding taps never appear.  LDS ring of NST stages; a stage holds one chunk: BM A rows + BN B rows of 128 bytes,
+// filled by LDS-DMA (global_load_lds_dwordx4: each wave-instruction writes 1 KiB = 8 rows).  Rows are unpadded --
+// the DMA write is lane-linear -- so the 16-byte slots of a row are XOR-swizzled by (row >> 1) & 7 on the SOURCE
+// address and on the fragment read, which makes ds_read_b128 conflict-free.  GroupNorm(1,C) on source 1 is folded
+// (plan.h): gamma lives in the weights, the accumulator rows are scaled by rstd after the last source-1 chunk and
+// the epilogue adds B1[p][n] - mean*rstd*S[p][n]; the K loop itself is a pure GEMM.
 // Every wave issues the same number IA of DMA instructions per chunk, so `s_waitcnt vmcnt((NST-2)*IA)` retires
 // exactly chunk i while NST-2 younger chunks stay in flight across the (raw) barrier.
 // Rows beyond the batch / beyond Npad are CLAMPED, K is padded to 32 with zero weights: the loop has no predicate.
 template <int BM, int BN, int NST, bool GN>
-__global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
+__global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
   constexpr int WM = BM / 64, WN = BN / 64;          // 32x32 MFMA tiles per wave in M and N (waves are 2 x 2)
   constexpr int ROWS = BM + BN;
   constexpr int NI = ROWS / 32;                      // DMA wave-instructions per wave per chunk (8 rows each)
   constexpr int RA = BM / 32;                        // the first RA of them carry A rows
-  constexpr int STAGE_F = ROWS * 32 + (GN ? 4 * 64 : 0);
-  constexpr int IA = NI + (GN ? 1 : 0);
-  constexpr int PER = WM + WN + (GN ? 2 : 0);        // ds_read_b128 per k-group of 8
+  constexpr int STAGE_F = ROWS * 32;
+  constexpr int IA = NI;
+  constexpr int PER = WM + WN;                       // ds_read_b128 per k-group of 8
   constexpr int NRD = 2 * PER;                       // ... per asm statement (two k-groups)
   constexpr int EP_LD = 32 * WN + 4;                 // epilogue transpose tile row stride (floats)
-  constexpr int LDS_F = NST * STAGE_F > 4 * 32 * EP_LD + 4 * BM ? NST * STAGE_F : 4 * 32 * EP_LD + 4 * BM;
+  constexpr int GN_SCRATCH = GN ? 256 * 4 + BM * 2 : 0;      // fp64 partial sums [256/BM][BM][2] + (mean, rstd)[BM]
+  constexpr int RING_F = NST * STAGE_F + GN_SCRATCH;
+  constexpr int LDS_F = RING_F > 4 * 32 * EP_LD + 4 * BM ? RING_F : 4 * 32 * EP_LD + 4 * BM;
   __shared__ __attribute__((aligned(1024))) float lds[LDS_F];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave >> 1, wave_n = wave & 1;
-  unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_wait = 0, st_issue = 0, st_comp = 0, st_a = 0, st_b = 0;
+  unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_wait = 0, st_comp = 0, st_a = 0, st_b = 0;
   if (g.dbg) st_t0 = __builtin_amdgcn_s_memtime();
   int bid = blockIdx.x;
   const int nt = bid % g.ntiles; bid /= g.ntiles;
   const int mt = bid % g.mtiles; const int p = bid / g.mtiles;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int oy = p / g.Wout, ox = p - oy * g.Wout;
   const int fi = lane & 31, fh = lane >> 5;
 
-  // ---- chunk count (wave-uniform) ----
-  int nvalid = 0;
-  {
-    int ky = 0, kx = 0;
-    for (int t = 0; t < g.KH * g.KW; ++t) {
-      nvalid += (g.a_bcast || tap_source_pixel(oy, ox, ky, kx, g.stride, g.pad, g.transposed, g.up, g.Ha, g.Wa) >= 0) ? 1 : 0;
-      if (++kx == g.KW) { kx = 0; ++ky; }
-    }
-  }
-  const int n1 = nvalid * (g.Kp >> 5);
-  const int total = n1 + (g.A2 ? (g.Kp2 >> 5) : 0);
-  const int p2 = (oy / g.up2) * g.W2w + (ox / g.up2);
-  const float* Wp = g.W + (long long)p * g.w_pix_stride;
+  const int4 hd = scalar_load16(g.hdr + p);                        // {first descriptor, chunk count, source-1 chunks, p2}
+  const int4* __restrict__ dsc = g.desc + hd.x;
+  const int total = hd.y;
 
-  // ---- GroupNorm(1,C) statistics of the block's BM rows from the producer's partial sums: all 256 threads
-  //      read partials (256/BM threads per row, loads batched so that they overlap), reduce through LDS ----
-  float gmean[WM], grstd[WM];
+  // ---- per-lane DMA source row offsets (loop invariant).  Lane l of instruction q = wave + 4j writes LDS row
+  //      r = 8q + (l >> 3), physical slot l & 7, and fetches logical slot ls = (l & 7) ^ ((r >> 1) & 7), which
+  //      does not depend on j. ----
+  const int rbase = 8 * wave + (lane >> 3);
+  const int ls4 = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 4;
+  int offs1[NI], offs2[NI];
 #pragma unroll
-  for (int a = 0; a < WM; ++a) { gmean[a] = 0.f; grstd[a] = 1.f; }
-  if constexpr (GN) {
-    constexpr int PL = 256 / BM;
-    const int r = tid % BM, pl = tid / BM;
-    const int b = min(m0 + r, g.B - 1);
-    double s = 0.0, q = 0.0;
-    int i = pl;
-    for (; i + 3 * PL < g.gn_nparts; i += 4 * PL) {
-      const float2 v0 = g.gn_part[(long long)i * g.B + b], v1 = g.gn_part[(long long)(i + PL) * g.B + b];
-      const float2 v2 = g.gn_part[(long long)(i + 2 * PL) * g.B + b], v3 = g.gn_part[(long long)(i + 3 * PL) * g.B + b];
-      s += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
-      q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+  for (int j = 0; j < NI; ++j) {
+    const int row = j < RA ? min(m0 + rbase + 32 * j, g.B - 1) : min(n0 + rbase + 32 * (j - RA), g.Npad - 1);
+    offs1[j] = row * (j < RA ? g.lda : g.Kp) + ls4;
+    offs2[j] = row * (j < RA ? g.lda2 : g.Kp2) + ls4;
+  }
+
+  // The DMA of one chunk is issued in IA pieces so that the pieces can be spread between the MFMA groups of the
+  // chunk being computed.  Piece 0 fetches the chunk's descriptor (scalar load) and resolves the bases.
+  int is_c = 0, is_stage = 0;
+  int4 is_next = scalar_load16(dsc);                 // descriptor of the next chunk to issue, loaded one chunk ahead
+  const float* is_a = g.A; const float* is_w = g.W;
+  bool is_src2 = false;
+  float* is_sbase = lds;
+  auto issue_piece = [&](int j) {
+    if (j == 0) {
+      const int4 d = is_next;
+      ++is_c;
+      is_next = scalar_load16(dsc + (is_c < total ? is_c : 0));
+      is_src2 = (d.w & 1) != 0;
+      is_a = (is_src2 ? g.A2 : g.A) + d.x;
+      is_w = (is_src2 ? g.W2 : g.W) + d.y;
+      is_sbase = lds + is_stage * STAGE_F + wave * 256;
+      is_stage = is_stage + 1 == NST ? 0 : is_stage + 1;
     }
-    for (; i < g.gn_nparts; i += PL) { const float2 v = g.gn_part[(long long)i * g.B + b]; s += v.x; q += v.y; }
-    double* red = reinterpret_cast<double*>(lds);            // [PL][BM][2]
+    const int o = is_src2 ? offs2[j] : offs1[j];
+    __builtin_amdgcn_global_load_lds((glb_void*)((j < RA ? is_a : is_w) + o), (lds_void*)(is_sbase + j * 1024), 16, 0, 0);
+  };
+
+  // ---- GroupNorm(1,C) statistics of the block's BM rows from the producer's partial sums: all 256 threads read
+  //      partials (256/BM threads per row).  The first 16 loads per thread are issued BEFORE the ring prefill so that
+  //      their latency hides behind the DMA issue; the sums are reduced through a scratch area behind the ring. ----
+  if (g.dbg) st_t1 = __builtin_amdgcn_s_memtime();
+  const GemmCold* __restrict__ cold = g.cold;
+  constexpr int PL = 256 / BM;
+  const int gr_r = tid % BM, gr_pl = tid / BM;
+  float2 gv[16];
+  int gn_nparts = 0;
+  const float2* gp = nullptr;
+  if constexpr (GN) {
+    gn_nparts = cold->gn_nparts;
+    gp = cold->gn_part + min(m0 + gr_r, g.B - 1);
+#pragma unroll
+    for (int u = 0; u < 16; ++u)          // clamped index, masked at summation: no select may sit between the loads
+      gv[u] = gp[(long long)min(gr_pl + u * PL, gn_nparts - 1) * g.B];
+  }
+
+  // ---- prefill the ring ----
+  int issued = 0;
+  for (; issued < total && issued < NST - 1; ++issued) {
+#pragma unroll
+    for (int j = 0; j < IA; ++j) issue_piece(j);
+  }
+  unsigned long long st_p1 = 0, st_p2 = 0, st_p3 = 0, st_p4 = 0;
+  if (g.dbg) st_p1 = __builtin_amdgcn_s_memtime();
+
+  float rrow[GN ? WM : 1][16];
+  if constexpr (GN) {
+    const int r = gr_r, pl = gr_pl;
+    double s = 0.0, q = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) if (pl + u * PL < gn_nparts) { s += (double)gv[u].x; q += (double)gv[u].y; }
+    for (int i = pl + 16 * PL; i < gn_nparts; i += 16 * PL) {
+      float2 v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = gp[(long long)min(i + u * PL, gn_nparts - 1) * g.B];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) if (i + u * PL < gn_nparts) { s += (double)v[u].x; q += (double)v[u].y; }
+    }
+    if (g.dbg) st_p2 = __builtin_amdgcn_s_memtime();
+    double* red = reinterpret_cast<double*>(lds + NST * STAGE_F);            // [PL][BM][2]
     red[(pl * BM + r) * 2] = s; red[(pl * BM + r) * 2 + 1] = q;
     __syncthreads();
-    float2* mr = reinterpret_cast<float2*>(lds + PL * BM * 4);   // [BM] (mean, rstd), behind the doubles
+    float2* mr = reinterpret_cast<float2*>(lds + NST * STAGE_F + PL * BM * 4);   // [BM] (mean, rstd)
     if (tid < BM) {
       double ss = 0.0, qq = 0.0;
 #pragma unroll
       for (int k = 0; k < PL; ++k) { ss += red[(k * BM + tid) * 2]; qq += red[(k * BM + tid) * 2 + 1]; }
-      const double mean = ss * (double)g.gn_inv_count;
-      double var = qq * (double)g.gn_inv_count - mean * mean;
+      const double inv = (double)cold->gn_inv_count;
+      const double mean = ss * inv;
+      double var = qq * inv - mean * mean;
       var = var < 0.0 ? 0.0 : var;
       mr[tid] = make_float2((float)mean, rsqrtf((float)var + 1e-5f));
     }
     __syncthreads();
+    // rstd of the 16 accumulator rows this lane holds per 32x32 tile (row = (r&3) + 8(r>>2) + 4 fh)
 #pragma unroll
-    for (int a = 0; a < WM; ++a) { const float2 v = mr[wave_m * 32 * WM + a * 32 + fi]; gmean[a] = v.x; grstd[a] = v.y; }
-    __syncthreads();                                           // the ring reuses this LDS
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rrow[a][r] = mr[wave_m * 32 * WM + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh].y;
   }
 
-  // ---- per-lane DMA source offsets for source 1 (loop invariant).  Lane l of instruction q = wave + 4j writes
-  //      LDS row r = 8q + (l >> 3), physical slot l & 7, and fetches logical slot ls = (l & 7) ^ ((r >> 1) & 7),
-  //      which does not depend on j. ----
-  const int rbase = 8 * wave + (lane >> 3);
-  const int ls4 = ((lane & 7) ^ ((4 * (wave & 1) + (lane >> 4)) & 7)) * 4;
-  int offs1[NI];
-#pragma unroll
-  for (int j = 0; j < NI; ++j)
-    offs1[j] = j < RA ? min(m0 + rbase + 32 * j, g.B - 1) * g.lda + ls4 : min(n0 + rbase + 32 * (j - RA), g.Npad - 1) * g.Kp + ls4;
-
-  ChunkWalk cw;
-  walk_init(g, cw, oy, ox);
-  auto issue_chunk = [&](int stage) {
-    float* sbase = lds + stage * STAGE_F + wave * 256;
-    if (cw.seg == 0) {
-      const float* abase = g.A + (long long)cw.q * g.B * g.lda + cw.kc;
-      const float* wbase = Wp + (long long)cw.t * g.Npad * g.Kp + cw.kc;
-#pragma unroll
-      for (int j = 0; j < NI; ++j)
-        __builtin_amdgcn_global_load_lds((glb_void*)((j < RA ? abase : wbase) + offs1[j]), (lds_void*)(sbase + j * 1024), 16, 0, 0);
-    } else {
-      const float* abase = g.A2 + (long long)p2 * g.B * g.lda2 + cw.kc;
-      const float* wbase = g.W2 + cw.kc;
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        const int o2 = j < RA ? min(m0 + rbase + 32 * j, g.B - 1) * g.lda2 + ls4 : min(n0 + rbase + 32 * (j - RA), g.Npad - 1) * g.Kp2 + ls4;
-        __builtin_amdgcn_global_load_lds((glb_void*)((j < RA ? abase : wbase) + o2), (lds_void*)(sbase + j * 1024), 16, 0, 0);
-      }
-    }
-    if constexpr (GN) {
-      // source-2 chunks carry no GroupNorm; they still fetch a (unused) gamma/beta to keep the vmcnt count uniform
-      const int kg = cw.seg == 0 ? cw.kc : 0;
-      if (lane < 16)
-        __builtin_amdgcn_global_load_lds((glb_void*)((lane < 8 ? g.gn_gamma : g.gn_beta) + kg + (lane & 7) * 4),
-                                         (lds_void*)(lds + stage * STAGE_F + ROWS * 32 + wave * 64), 16, 0, 0);
-    }
-    walk_advance(g, cw, oy, ox);
-  };
-
+  if (g.dbg) st_p3 = __builtin_amdgcn_s_memtime();
   // ---- consumer side: per-lane LDS byte addresses of the fragments (loop invariant within a stage) ----
   const unsigned lds_base = (unsigned)(unsigned long long)(lds_void*)lds;
-  unsigned fa_off[WM][4], fb_off[WN][4], gb_off[4];
+  unsigned fa_off[WM][4], fb_off[WN][4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
     for (int a = 0; a < WM; ++a) { const int r = wave_m * 32 * WM + a * 32 + fi; fa_off[a][kk] = r * 128 + (((2 * kk + fh) ^ ((r >> 1) & 7)) * 16); }
 #pragma unroll
     for (int b = 0; b < WN; ++b) { const int r = BM + wave_n * 32 * WN + b * 32 + fi; fb_off[b][kk] = r * 128 + (((2 * kk + fh) ^ ((r >> 1) & 7)) * 16); }
-    gb_off[kk] = ROWS * 128 + wave * 256 + kk * 32 + fh * 16;
   }
 
   f32x16 acc[WM][WN];
@@ -278,11 +252,6 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (g.dbg) st_t1 = __builtin_amdgcn_s_memtime();
-  int issued = 0, istage = 0;
-  for (; issued < total && issued < NST - 1; ++issued) { issue_chunk(istage); istage = istage + 1 == NST ? 0 : istage + 1; }
-
-  // one k-pair (two groups of 8 k): gather the read addresses / consume the fragments
   auto addrs = [&](unsigned sb, int kp, unsigned* ad) {
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
@@ -291,10 +260,11 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
       for (int a = 0; a < WM; ++a) ad[h2 * PER + a] = sb + fa_off[a][kk];
 #pragma unroll
       for (int b = 0; b < WN; ++b) ad[h2 * PER + WM + b] = sb + fb_off[b][kk];
-      if constexpr (GN) { ad[h2 * PER + WM + WN] = sb + gb_off[kk]; ad[h2 * PER + WM + WN + 1] = sb + gb_off[kk] + 128; }
     }
   };
-  auto consume = [&](const f32x4* rd, bool apply_gn) {
+  // consume one k-pair (two groups of 8 k); behind each group's MFMAs issue DMA pieces gq, gq + 4, ... of the chunk
+  // NST - 1 ahead (gq = 2 kp + h2)
+  auto consume = [&](const f32x4* rd, int kp, bool do_issue) {
 #pragma unroll
     for (int h2 = 0; h2 < 2; ++h2) {
       f32x4 fa[WM], fb[WN];
@@ -302,16 +272,6 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
       for (int a = 0; a < WM; ++a) fa[a] = rd[h2 * PER + a];
 #pragma unroll
       for (int b = 0; b < WN; ++b) fb[b] = rd[h2 * PER + WM + b];
-      if constexpr (GN) {
-        if (apply_gn) {
-          const f32x4 ga = rd[h2 * PER + WM + WN], be = rd[h2 * PER + WM + WN + 1];
-#pragma unroll
-          for (int a = 0; a < WM; ++a) {
-            const f32x4 s = ga * grstd[a];
-            fa[a] = fa[a] * s + (be - s * gmean[a]);   // (x - mean) * rstd * gamma + beta; padded k have gamma = beta = 0
-          }
-        }
-      }
 #pragma unroll
       for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -321,98 +281,153 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmArgs g) {
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].z, fb[b].z, acc[a][b], 0, 0, 0);
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a].w, fb[b].w, acc[a][b], 0, 0, 0);
         }
+      if (do_issue) {
+#pragma unroll
+        for (int j = kp * 2 + h2; j < IA; j += 4) issue_piece(j);
+      }
     }
   };
 
+  if (g.dbg) st_p4 = __builtin_amdgcn_s_memtime();
   int cstage = 0;
-  for (int i = 0; i < total; ++i) {
-    if (g.dbg) st_a = __builtin_amdgcn_s_memtime();
-    if (issued - (i + 1) >= NST - 2) wait_vmcnt<(NST - 2) * IA>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();            // chunk i landed for every wave; everyone is done with chunk i-1
-    if (g.dbg) { st_b = __builtin_amdgcn_s_memtime(); st_wait += st_b - st_a; }
-    if (issued < total) { issue_chunk(istage); istage = istage + 1 == NST ? 0 : istage + 1; ++issued; }
-    if (g.dbg) { st_a = __builtin_amdgcn_s_memtime(); st_issue += st_a - st_b; }
-    const unsigned sb = lds_base + (unsigned)(cstage * STAGE_F * 4);
-    cstage = cstage + 1 == NST ? 0 : cstage + 1;
-    const bool apply_gn = GN && i < n1;
-    f32x4 r0[NRD], r1[NRD]; unsigned ad[NRD];
-    addrs(sb, 0, ad); lds_issue<NRD>(r0, ad);
-    addrs(sb, 1, ad);
-    lds_wait<NRD>(r0);
-    lds_issue<NRD>(r1, ad);                   // the second k-pair's reads fly under the first pair's MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-    consume(r0, apply_gn);
-    __builtin_amdgcn_sched_barrier(0);
-    lds_wait<NRD>(r1);
-    __builtin_amdgcn_sched_barrier(0);
-    consume(r1, apply_gn);
-    if (g.dbg) { st_b = __builtin_amdgcn_s_memtime(); st_comp += st_b - st_a; }
+  // The K loop proper.  It runs twice: over the source-1 chunks, then (after the folded-GroupNorm row scaling, which
+  // must not sit inside the loop or hipcc keeps the accumulators in VGPRs and copies them to AGPRs every trip)
+  // over the source-2 chunks.
+  auto run_chunks = [&](int i0, int i1) {
+    for (int i = i0; i < i1; ++i) {
+      if (g.dbg) st_a = __builtin_amdgcn_s_memtime();
+      if (issued - (i + 1) >= NST - 2) wait_vmcnt<(NST - 2) * IA>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();            // chunk i landed for every wave; everyone is done with chunk i-1
+      if (g.dbg) { st_b = __builtin_amdgcn_s_memtime(); st_wait += st_b - st_a; }
+      const bool do_issue = issued < total;
+      if (do_issue) ++issued;
+      const unsigned sb = lds_base + (unsigned)(cstage * STAGE_F * 4);
+      cstage = cstage + 1 == NST ? 0 : cstage + 1;
+      f32x4 r0[NRD], r1[NRD]; unsigned ad[NRD];
+      addrs(sb, 0, ad); lds_issue<NRD>(r0, ad);
+      addrs(sb, 1, ad);
+      lds_wait<NRD>(r0);
+      lds_issue<NRD>(r1, ad);                   // the second k-pair's reads fly under the first pair's MFMAs
+      __builtin_amdgcn_sched_barrier(0);
+      consume(r0, 0, do_issue);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_wait<NRD>(r1);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(r1, 1, do_issue);
+      if (g.dbg) { st_a = __builtin_amdgcn_s_memtime(); st_comp += st_a - st_b; }
+    }
+  };
+  if constexpr (GN) {
+    run_chunks(0, hd.z);
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int b = 0; b < WN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] *= rrow[a][r];
+    run_chunks(hd.z, total);
+  } else {
+    run_chunks(0, total);
   }
   if (g.dbg) st_t2 = __builtin_amdgcn_s_memtime();
   __syncthreads();      // all DMA retired (last wait was vmcnt(0)); LDS is reused by the epilogue
 
   // ---- epilogue: out = act(acc + bias + r) and per-row partial (sum, sumsq).  Each wave transposes its 32-row
-  //      tile through LDS so that a lane owns 16*WN CONSECUTIVE columns of one row: the residual is read and the
-  //      result written as float4, and the row statistics are lane-local sums plus one cross-half shuffle. ----
-  const float* biasp = g.bias ? g.bias + (long long)p * g.bias_pix_stride : nullptr;
+  //      tile through LDS; then 8*WN consecutive lanes own one row (each lane 4 consecutive columns), so every global
+  //      access is a full 128*WN-byte row segment.  A lane's column is fixed across the passes: bias-like vectors
+  //      (folded-GroupNorm S / B1) are loaded once, and all residual loads are issued before the first store. ----
+  const GemmCold c = *cold;
+  const int p2 = hd.w;
+  const int oy = p / c.Wout, ox = p - oy * c.Wout;
+  const float* biasp = c.bias ? c.bias + (long long)p * c.bias_pix_stride : nullptr;
   float* tile = lds + wave * 32 * EP_LD;
   float* srow = lds + 4 * 32 * EP_LD;        // [2 (wave_n)][BM][2]
-  const bool want_stats = g.stat_out != nullptr;
-  const int erow = lane & 31, ehalf = lane >> 5;
+  const bool want_stats = c.stat_out != nullptr;
+  constexpr int LPR = 8 * WN, RPI = 64 / LPR, NPASS = 32 / RPI;    // lanes per row, rows per pass, passes
+  const int ecol = (lane % LPR) * 4, erow0 = lane / LPR;
+  const int n = n0 + wave_n * 32 * WN + ecol;                       // this lane's first global column
+  const bool ncol = n < c.nstore;
+  float4 gs = make_float4(0.f, 0.f, 0.f, 0.f), gb = gs;
+  if constexpr (GN) {
+    if (ncol && !c.out_nchw) {
+      gs = *reinterpret_cast<const float4*>(c.gn_s + (long long)p * g.Npad + n);
+      gb = *reinterpret_cast<const float4*>(c.gn_b1 + (long long)p * g.Npad + n);
+    }
+  }
+  const float2* mrp = reinterpret_cast<const float2*>(lds + NST * STAGE_F + (GN ? 256 * 4 : 0));
 #pragma unroll
   for (int a = 0; a < WM; ++a) {
 #pragma unroll
     for (int b = 0; b < WN; ++b) {
-      const int n = n0 + wave_n * 32 * WN + b * 32 + fi;
-      const float bv = (biasp && n < g.Npad) ? biasp[n] : 0.f;
+      const int nb = n0 + wave_n * 32 * WN + b * 32 + fi;
+      const float bv = (biasp && nb < g.Npad) ? biasp[nb] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * fh) * EP_LD + b * 32 + fi] = acc[a][b][r] + bv;
     }
     // wave-local: LDS operations of one wave complete in order, no barrier needed
-    const int bb = m0 + wave_m * 32 * WM + a * 32 + erow;
-    const int ncol0 = n0 + wave_n * 32 * WN + ehalf * 16 * WN;
-    float s = 0.f, q = 0.f;
-    if (bb < g.B) {
-      const float* rrow = g.R ? g.R + ((long long)p2 * g.B + bb) * g.ldr : nullptr;
+    const int mbase = wave_m * 32 * WM + a * 32;
+    if (!c.out_nchw) {
+      float4 rv[NPASS];
+      if (c.R) {
 #pragma unroll
-      for (int c4 = 0; c4 < 4 * WN; ++c4) {
-        const int n = ncol0 + c4 * 4;
-        float4 v = *reinterpret_cast<const float4*>(tile + erow * EP_LD + ehalf * 16 * WN + c4 * 4);
-        if (!g.out_nchw) {
-          if (n < g.nstore) {
-            if (rrow) { const float4 rv = *reinterpret_cast<const float4*>(rrow + n); v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
-            v.x = act_apply(g.act, v.x); v.y = act_apply(g.act, v.y); v.z = act_apply(g.act, v.z); v.w = act_apply(g.act, v.w);
-            *reinterpret_cast<float4*>(g.out + ((long long)p * g.B + bb) * g.ldo + n) = v;
-            s += (v.x + v.y) + (v.z + v.w); q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-          }
-        } else {
-          const int y = oy - g.crop_y, x = ox - g.crop_x;
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < g.nstore && y >= 0 && y < g.Hn && x >= 0 && x < g.Wn) {
-              float u = vv[e];
-              if (rrow) u += rrow[n + e];
-              g.out[(((long long)bb * g.N + n + e) * g.Hn + y) * g.Wn + x] = act_apply(g.act, u);
-            }
+        for (int t = 0; t < NPASS; ++t) {
+          const int bb = m0 + mbase + t * RPI + erow0;
+          rv[t] = (ncol && bb < g.B) ? *reinterpret_cast<const float4*>(c.R + ((long long)p2 * g.B + bb) * c.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
-    }
-    if (want_stats) {
-      s += __shfl_xor(s, 32); q += __shfl_xor(q, 32);
-      if (ehalf == 0) { const int ml = wave_m * 32 * WM + a * 32 + erow; srow[(wave_n * BM + ml) * 2] = s; srow[(wave_n * BM + ml) * 2 + 1] = q; }
+#pragma unroll
+      for (int t = 0; t < NPASS; ++t) {
+        const int row = t * RPI + erow0, bb = m0 + mbase + row;
+        float4 v = *reinterpret_cast<const float4*>(tile + row * EP_LD + ecol);
+        float s = 0.f, q = 0.f;
+        if (ncol && bb < g.B) {
+          if constexpr (GN) {
+            const float2 mrv = mrp[mbase + row]; const float mrs = mrv.x * mrv.y;
+            v.x += gb.x - mrs * gs.x; v.y += gb.y - mrs * gs.y; v.z += gb.z - mrs * gs.z; v.w += gb.w - mrs * gs.w;
+          }
+          if (c.R) { v.x += rv[t].x; v.y += rv[t].y; v.z += rv[t].z; v.w += rv[t].w; }
+          v.x = act_apply(c.act, v.x); v.y = act_apply(c.act, v.y); v.z = act_apply(c.act, v.z); v.w = act_apply(c.act, v.w);
+          *reinterpret_cast<float4*>(g.out + ((long long)p * g.B + bb) * c.ldo + n) = v;
+          s = (v.x + v.y) + (v.z + v.w); q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+        if (want_stats) {
+#pragma unroll
+          for (int o = 1; o < LPR; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+          if ((lane % LPR) == 0) { srow[(wave_n * BM + mbase + row) * 2] = s; srow[(wave_n * BM + mbase + row) * 2 + 1] = q; }
+        }
+      }
+    } else {
+      // external NCHW output (final layers; N is tiny): per-element scatter
+      const int y = oy - c.crop_y, x = ox - c.crop_x;
+#pragma unroll
+      for (int t = 0; t < NPASS; ++t) {
+        const int row = t * RPI + erow0, bb = m0 + mbase + row;
+        const float4 v = *reinterpret_cast<const float4*>(tile + row * EP_LD + ecol);
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+        float mrs = 0.f;
+        if constexpr (GN) { const float2 mrv = mrp[mbase + row]; mrs = mrv.x * mrv.y; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (bb < g.B && n + e < c.nstore && y >= 0 && y < c.Hn && x >= 0 && x < c.Wn) {
+            float u = vv[e];
+            if constexpr (GN) u += c.gn_b1[(long long)p * g.Npad + n + e] - mrs * c.gn_s[(long long)p * g.Npad + n + e];
+            if (c.R) u += c.R[((long long)p2 * g.B + bb) * c.ldr + n + e];
+            g.out[(((long long)bb * c.N + n + e) * c.Hn + y) * c.Wn + x] = act_apply(c.act, u);
+          }
+      }
     }
   }
   if (want_stats) {
     __syncthreads();
     if (tid < BM && m0 + tid < g.B) {
       const float s = srow[tid * 2] + srow[(BM + tid) * 2], q = srow[tid * 2 + 1] + srow[(BM + tid) * 2 + 1];
-      g.stat_out[((long long)p * g.ntiles + nt) * g.B + m0 + tid] = make_float2(s, q);
+      c.stat_out[((long long)p * g.ntiles + nt) * g.B + m0 + tid] = make_float2(s, q);
     }
   }
   if (g.dbg && tid == 0 && (int)blockIdx.x == (int)(gridDim.x / 2)) {
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-    g.dbg[0] = st_t1 - st_t0; g.dbg[1] = st_t2 - st_t1; g.dbg[2] = t3 - st_t2; g.dbg[3] = st_wait; g.dbg[4] = st_issue; g.dbg[5] = st_comp;
+    g.dbg[0] = st_t1 - st_t0; g.dbg[1] = st_t2 - st_t1; g.dbg[2] = t3 - st_t2; g.dbg[3] = st_wait; g.dbg[4] = 0; g.dbg[5] = st_comp;
+    g.dbg[8] = st_p1 - st_t1; g.dbg[9] = st_p2 - st_p1; g.dbg[10] = st_p3 - st_p2; g.dbg[11] = st_p4 - st_p3;
     g.dbg[6] = (unsigned long long)total; g.dbg[7] = gridDim.x;
   }
 }
@@ -644,33 +659,43 @@ __global__ void bilinear_kernel(const BilArgs o) {
 // ------------------------------------------------------------------------------------------------
 unsigned long long* g_gemm_dbg = nullptr;   // set by sbm_debug_gemm_stamps (diagnostics only)
 
-static const char* launch_gemm(const GemmOp& o, const float* prm, float* ws, const float* ext_in, float* ext_out, hipStream_t st) {
-  GemmArgs g{};
-  g.A = (o.a_ext ? ext_in : ws) + o.a.off;
-  g.W = prm + o.w_off;
-  g.A2 = o.has2 ? ws + o.a2.off : nullptr; g.W2 = o.has2 ? prm + o.w2_off : nullptr;
-  g.bias = o.bias_off >= 0 ? prm + o.bias_off : nullptr;
-  g.R = o.has_res ? ws + o.r.off : nullptr;
-  g.out = o.out_nchw ? ext_out : ws + o.out.off;
-  g.gn_part = o.gn ? reinterpret_cast<const float2*>(ws + o.gn_part_off) : nullptr;
-  g.gn_gamma = o.gn ? prm + o.gn_gamma_off : nullptr; g.gn_beta = o.gn ? prm + o.gn_beta_off : nullptr;
-  g.stat_out = o.stat_off >= 0 ? reinterpret_cast<float2*>(ws + o.stat_off) : nullptr;
-  g.w_pix_stride = o.w_pix_stride; g.bias_pix_stride = o.bias_pix_stride;
-  g.B = o.B; g.Hout = o.Hout; g.Wout = o.Wout;
-  g.lda = o.a.ld; g.Kp = o.Kp; g.Ha = o.a.H; g.Wa = o.a.W; g.up = o.up; g.KH = o.KH; g.KW = o.KW; g.stride = o.stride; g.pad = o.pad;
-  g.transposed = o.transposed; g.a_bcast = o.a_bcast;
-  g.gn_nparts = o.gn_nparts; g.gn_inv_count = o.gn_inv_count;
-  g.lda2 = o.a2.ld; g.Kp2 = o.Kp2; g.up2 = o.up2; g.W2w = o.has2 ? o.a2.W : (o.has_res ? o.r.W : 1);
-  g.ldr = o.r.ld;
-  g.act = o.act; g.ldo = o.out.ld; g.nstore = o.out_nchw ? o.N : o.out.C; g.Npad = o.Npad; g.out_nchw = o.out_nchw; g.N = o.N;
-  g.crop_y = o.crop_y; g.crop_x = o.crop_x; g.Hn = o.Hn; g.Wn = o.Wn;
-  g.mtiles = ceil_div(o.B, o.BM); g.ntiles = ceil_div(g.nstore, o.BN);
-  g.dbg = g_gemm_dbg;
+// Resolve one GEMM op into its kernel arguments (done once per model, not per launch).
+const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, float* ws, const GemmCold* cold_dev, GemmHot* hot, GemmCold* cold) {
   if ((o.a.ld & 3) || (o.has2 && (o.a2.ld & 3))) return "seg_gemm: row pitches must be multiples of 4 floats";
   if (o.Kp <= 0 || (o.Kp & 31) || (o.has2 && (o.Kp2 <= 0 || (o.Kp2 & 31)))) return "seg_gemm: weight K stride must be a positive multiple of 32";
   if (o.a_ext && o.a.C != o.Kp) return "seg_gemm: an external input matrix must have a multiple of 32 columns";
   if ((long long)o.B * (o.a.ld > o.a2.ld ? o.a.ld : o.a2.ld) >= (1LL << 30) || (long long)o.Npad * (o.Kp > o.Kp2 ? o.Kp : o.Kp2) >= (1LL << 30))
     return "seg_gemm: operand plane too large for 32-bit lane offsets";
+  if (o.hdr_off < 0 || o.desc_off < 0 || plan.ident_off < 0) return "seg_gemm: chunk tables missing";
+  if (!((o.BM == 64 && o.BN == 64) || (o.BM == 128 && o.BN == 64) || (o.BM == 128 && o.BN == 128))) return "seg_gemm: unsupported tile";
+  GemmHot h{};
+  h.A = o.a_ext ? nullptr : ws + o.a.off;            // external input patched at launch
+  h.A2 = o.has2 ? ws + o.a2.off : nullptr;
+  h.W = prm + o.w_off; h.W2 = o.has2 ? prm + o.w2_off : nullptr;
+  h.desc = reinterpret_cast<const int4*>(prm + o.desc_off); h.hdr = reinterpret_cast<const int4*>(prm + o.hdr_off);
+  h.cold = cold_dev;
+  h.out = o.out_nchw ? nullptr : ws + o.out.off;     // external output patched at launch
+  h.B = o.B; h.lda = o.a.ld; h.lda2 = o.a2.ld; h.Kp = o.Kp; h.Kp2 = o.Kp2; h.Npad = o.Npad;
+  const int nstore = o.out_nchw ? o.N : o.out.C;
+  h.mtiles = ceil_div(o.B, o.BM); h.ntiles = ceil_div(nstore, o.BN);
+  h.dbg = nullptr;
+  GemmCold c{};
+  c.bias = o.bias_off >= 0 ? prm + o.bias_off : nullptr;
+  c.R = o.has_res ? ws + o.r.off : nullptr;
+  c.gn_part = o.gn ? reinterpret_cast<const float2*>(ws + o.gn_part_off) : nullptr;
+  c.gn_s = o.gn ? prm + o.gn_s_off : nullptr; c.gn_b1 = o.gn ? prm + o.gn_b1_off : nullptr;
+  c.stat_out = o.stat_off >= 0 ? reinterpret_cast<float2*>(ws + o.stat_off) : nullptr;
+  c.bias_pix_stride = o.bias_pix_stride; c.gn_nparts = o.gn_nparts; c.gn_inv_count = o.gn_inv_count;
+  c.ldr = o.r.ld; c.act = o.act; c.ldo = o.out.ld; c.nstore = nstore; c.out_nchw = o.out_nchw; c.N = o.N;
+  c.crop_y = o.crop_y; c.crop_x = o.crop_x; c.Hn = o.Hn; c.Wn = o.Wn; c.Wout = o.Wout;
+  *hot = h; *cold = c;
+  return nullptr;
+}
+
+static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, float* ext_out, hipStream_t st) {
+  if (o.a_ext) g.A = ext_in + o.a.off;
+  if (o.out_nchw) g.out = ext_out;
+  g.dbg = g_gemm_dbg;
   const long long blocks = (long long)o.Hout * o.Wout * g.mtiles * g.ntiles;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return "seg_gemm: bad grid";
   dim3 grid((unsigned)blocks), block(256);
@@ -680,15 +705,15 @@ static const char* launch_gemm(const GemmOp& o, const float* prm, float* ws, con
        else hipLaunchKernelGGL((seg_gemm<BM_, BN_, NST_, false>), grid, block, 0, st, g); } while (0)
   if (o.BM == 64 && o.BN == 64) SBM_LAUNCH(64, 64, 4);
   else if (o.BM == 128 && o.BN == 64) SBM_LAUNCH(128, 64, 4);
-  else if (o.BM == 128 && o.BN == 128) SBM_LAUNCH(128, 128, 3);
-  else return "seg_gemm: unsupported tile";
+  else SBM_LAUNCH(128, 128, 3);
 #undef SBM_LAUNCH
   return nullptr;
 }
 
-const char* launch_op(const Plan& plan, const Op& op, const float* prm, float* ws, const float* ext_in, float* ext_out, hipStream_t st) {
+const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ext_out, hipStream_t st) {
+  const Plan& plan = *dp.plan; const Op& op = plan.ops[idx]; const float* prm = dp.prm; float* ws = dp.ws;
   switch (op.kind) {
-    case OP_GEMM: return launch_gemm(op.g, prm, ws, ext_in, ext_out, st);
+    case OP_GEMM: return launch_gemm(op.g, dp.hot[idx], ext_in, ext_out, st);
     case OP_DWCONV7: {
       const DwOp& o = op.dw; DwArgs d{};
       d.in = ws + o.in.off; d.out = ws + o.out.off; d.w = prm + o.w_off; d.bias = prm + o.bias_off;
@@ -732,11 +757,12 @@ const char* launch_op(const Plan& plan, const Op& op, const float* prm, float* w
   return nullptr;
 }
 
-const char* run_plan(const Plan& plan, const float* prm, float* ws, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st) {
-  if (plan.time_off >= 0 && t_dev && t_dev != ws + plan.time_off)
-    if (hipMemcpyAsync(ws + plan.time_off, t_dev, sizeof(float) * plan.B, hipMemcpyDeviceToDevice, st) != hipSuccess) return "time copy failed";
-  for (const Op& op : plan.ops) {
-    const char* e = launch_op(plan, op, prm, ws, ext_in, ext_out, st);
+const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st) {
+  const Plan& plan = *dp.plan;
+  if (plan.time_off >= 0 && t_dev && t_dev != dp.ws + plan.time_off)
+    if (hipMemcpyAsync(dp.ws + plan.time_off, t_dev, sizeof(float) * plan.B, hipMemcpyDeviceToDevice, st) != hipSuccess) return "time copy failed";
+  for (int i = 0; i < (int)plan.ops.size(); ++i) {
+    const char* e = launch_op(dp, i, ext_in, ext_out, st);
     if (e) return e;
   }
   if (hipGetLastError() != hipSuccess) return "kernel launch failed";

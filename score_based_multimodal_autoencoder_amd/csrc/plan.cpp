@@ -252,7 +252,7 @@ class Builder {
   // ---- weight packing ----
   // conv weight [Cout][Cin][KH][KW] (or transposed-conv [Cin][Cout][KH][KW]) -> [tap][Npad][Ca]
   std::vector<float> pack_conv(const float* w, int cout, int cin, int kh, int kw, const ChanMap& cm, int Ca, int Npad,
-                               bool transposed, const std::vector<double>* out_scale = nullptr) {
+                               bool transposed, const std::vector<double>* out_scale = nullptr, const float* in_scale = nullptr) {
     std::vector<float> o((size_t)kh * kw * Npad * Ca, 0.f);
     for (int n = 0; n < cout; ++n)
       for (int c = 0; c < cin; ++c)
@@ -260,6 +260,7 @@ class Builder {
           size_t src = transposed ? (((size_t)c * cout + n) * kh * kw + t) : (((size_t)n * cin + c) * kh * kw + t);
           double v = w[src];
           if (out_scale) v *= (*out_scale)[n];
+          if (in_scale) v *= (double)in_scale[c];
           o[((size_t)t * Npad + n) * Ca + cm.idx[c]] = (float)v;
         }
     return o;
@@ -308,15 +309,37 @@ class Builder {
     const int nstore = s.out_nchw ? s.cout : pad8(s.cout);
     g.Npad = round_up(nstore, 32);
     g.Kp = round_up(s.a.C, 32);
-    g.w_off = add_params(pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, g.Kp, g.Npad, s.transposed, s.out_scale));
+    g.w_off = add_params(pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, g.Kp, g.Npad, s.transposed, s.out_scale, s.gn ? s.gamma : nullptr));
     std::vector<double> bias(g.Npad, 0.0);
     bool any_bias = false;
     if (s.bias) { for (int n = 0; n < s.cout; ++n) bias[n] += (s.out_scale ? (*s.out_scale)[n] : 1.0) * s.bias[n]; any_bias = true; }
     if (s.out_shift) { for (int n = 0; n < s.cout; ++n) bias[n] += (*s.out_shift)[n]; any_bias = true; }
     if (s.gn) {
       g.gn = 1; g.gn_part_off = s.gn_part; g.gn_nparts = s.gn_nparts; g.gn_inv_count = s.gn_inv;
-      g.gn_gamma_off = add_params(pack_vec(s.gamma, s.cin_true, &s.cm, g.Kp));
-      g.gn_beta_off = add_params(pack_vec(s.beta, s.cin_true, &s.cm, g.Kp));
+      // per-tap column sums of W*gamma and W*beta, then per-pixel sums over the valid taps
+      const int ntap = s.kh * s.kw, P = s.Hout * s.Wout;
+      std::vector<double> c2((size_t)ntap * g.Npad, 0.0), c1((size_t)ntap * g.Npad, 0.0);
+      for (int n = 0; n < s.cout; ++n)
+        for (int c = 0; c < s.cin_true; ++c)
+          for (int t = 0; t < ntap; ++t) {
+            const size_t src = s.transposed ? (((size_t)c * s.cout + n) * ntap + t) : (((size_t)n * s.cin_true + c) * ntap + t);
+            const double w = (double)s.w[src] * (s.out_scale ? (*s.out_scale)[n] : 1.0);
+            c2[(size_t)t * g.Npad + n] += w * (double)s.gamma[c];
+            c1[(size_t)t * g.Npad + n] += w * (double)s.beta[c];
+          }
+      std::vector<float> S((size_t)P * g.Npad, 0.f), B1((size_t)P * g.Npad, 0.f);
+      for (int p = 0; p < P; ++p) {
+        const int oy = p / s.Wout, ox = p % s.Wout;
+        std::vector<double> ss(g.Npad, 0.0), bb(g.Npad, 0.0);
+        for (int ky = 0; ky < s.kh; ++ky) for (int kx = 0; kx < s.kw; ++kx) {
+          if (tap_source_pixel(oy, ox, ky, kx, s.stride, s.pad, s.transposed ? 1 : 0, s.up, s.a.H, s.a.W) < 0) continue;
+          const int t = ky * s.kw + kx;
+          for (int n = 0; n < g.Npad; ++n) { ss[n] += c2[(size_t)t * g.Npad + n]; bb[n] += c1[(size_t)t * g.Npad + n]; }
+        }
+        for (int n = 0; n < g.Npad; ++n) { S[(size_t)p * g.Npad + n] = (float)ss[n]; B1[(size_t)p * g.Npad + n] = (float)bb[n]; }
+      }
+      g.gn_s_off = add_params(S);
+      g.gn_b1_off = add_params(B1);
     }
     if (s.has2) {
       g.has2 = 1; g.a2 = s.a2; g.up2 = s.up2;
@@ -637,10 +660,60 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       g.w_off = b.add_params(cond_w); g.Kp = td_p;
       g.bias_off = b.add_params(cond_b);
     }
+    finalize_gemm_tables(plan);
     return true;
   } catch (const std::exception& e) {
     plan->error = e.what();
     return false;
+  }
+}
+
+void finalize_gemm_tables(Plan* plan) {
+  auto add_ints = [&](const std::vector<int>& v) {
+    const int64_t off = (int64_t)plan->params.size();
+    plan->params.resize(plan->params.size() + v.size());
+    std::memcpy(plan->params.data() + off, v.data(), v.size() * sizeof(int));
+    while (plan->params.size() % 4) plan->params.push_back(0.f);
+    return off;
+  };
+  {
+    const int64_t off = (int64_t)plan->params.size();
+    for (int i = 0; i < 32; ++i) plan->params.push_back(1.f);
+    for (int i = 0; i < 32; ++i) plan->params.push_back(0.f);
+    plan->ident_off = off;
+  }
+  auto chk = [](int64_t v) { if (v < 0 || v > 0x7fffffffLL) throw std::runtime_error("plan: operand offset does not fit 32 bits"); return (int)v; };
+  for (Op& op : plan->ops) {
+    if (op.kind != OP_GEMM) continue;
+    GemmOp& g = op.g;
+    const int P = g.Hout * g.Wout;
+    std::vector<int> hdr((size_t)4 * P), desc;
+    for (int p = 0; p < P; ++p) {
+      const int oy = p / g.Wout, ox = p % g.Wout;
+      const int first = (int)(desc.size() / 4);
+      int n1 = 0;
+      for (int ky = 0; ky < g.KH; ++ky) for (int kx = 0; kx < g.KW; ++kx) {
+        const int q = g.a_bcast ? 0 : tap_source_pixel(oy, ox, ky, kx, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W);
+        if (q < 0) continue;
+        for (int kc = 0; kc < g.Kp; kc += 32) {
+          desc.push_back(chk((int64_t)q * g.B * g.a.ld + kc));
+          desc.push_back(chk((int64_t)p * g.w_pix_stride + (int64_t)(ky * g.KW + kx) * g.Npad * g.Kp + kc));
+          desc.push_back(kc);
+          desc.push_back(0);
+          ++n1;
+        }
+      }
+      const int w2 = g.has2 ? g.a2.W : (g.has_res ? g.r.W : 1);
+      const int p2 = (oy / g.up2) * w2 + (ox / g.up2);
+      if (g.has2)
+        for (int kc = 0; kc < g.Kp2; kc += 32) {
+          desc.push_back(chk((int64_t)p2 * g.B * g.a2.ld + kc)); desc.push_back(kc); desc.push_back(-1); desc.push_back(1);
+        }
+      hdr[4 * p] = first; hdr[4 * p + 1] = (int)(desc.size() / 4) - first; hdr[4 * p + 2] = n1; hdr[4 * p + 3] = p2;
+    }
+    if (desc.empty()) desc.assign(4, 0);
+    g.hdr_off = add_ints(hdr);
+    g.desc_off = add_ints(desc);
   }
 }
 
@@ -739,6 +812,7 @@ bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const
     if (o.H != cfg.size_in) throw std::runtime_error("plan: decoder geometry does not reach size_in");
     b.emit_conv(fc);
     b.free_act(o);
+    finalize_gemm_tables(plan);
     return true;
   } catch (const std::exception& e) {
     plan->error = e.what();
@@ -773,6 +847,7 @@ bool build_attrdec_plan(const AttrDecCfg& cfg, int B, int z_ld, const float* con
     c.out_nchw = true; c.Hn = c.Wn = 1;
     b.emit_conv(c);
     b.free_act(h);
+    finalize_gemm_tables(plan);
     return true;
   } catch (const std::exception& e) {
     plan->error = e.what();

@@ -58,7 +58,10 @@ struct GemmOp {
   int64_t gn_part_off = 0;   // workspace: float2 [gn_nparts][B] (sum, sumsq)
   int gn_nparts = 0;
   float gn_inv_count = 0.f;  // 1 / (true channels * pixels)
-  int64_t gn_gamma_off = 0, gn_beta_off = 0;  // params [a.C]
+  // GroupNorm is folded algebraically:  conv(GN(h))[m,n] = rstd_m * conv_{W*gamma}(h)[m,n] - mean_m*rstd_m * S[p][n] + B1[p][n]
+  // with S[p][n] = sum over the VALID taps of pixel p and over k of gamma_k W[t][n][k], B1 likewise with beta_k.  The
+  // packed weights at w_off already carry gamma; S and B1 are host tables [P_out][Npad].
+  int64_t gn_s_off = -1, gn_b1_off = -1;
   // source 2: fused 1x1 convolution of a second tensor at the same output pixel (ConvNeXt res_conv,
   // RBlock size_conv)
   int has2 = 0;
@@ -78,6 +81,11 @@ struct GemmOp {
   int crop_y = 0, crop_x = 0, Hn = 0, Wn = 0;  // out_nchw: crop of the padded grid
   int64_t stat_off = -1;  // workspace: float2 [P_out * ntiles][B] partial (sum, sumsq) of the stored rows
   int BM = 64, BN = 64;   // tile configuration (fixes ntiles = ceil(out.C / BN))
+  // Host-built chunk tables (params arena, stored as int32 bit patterns): the kernel walks K in 32-wide chunks and
+  // reads one 16-byte descriptor per chunk instead of doing tap geometry on the device.
+  //   hdr [P_out] x {first descriptor, chunk count, source-1 chunk count, residual / source-2 pixel p2}
+  //   desc[...]  x {A float offset, W float offset, gamma/beta K offset or -1, flags (bit 0: source 2)}
+  int64_t hdr_off = -1, desc_off = -1;
   int Kp = 0, Kp2 = 0;    // K stride of the weight rows of source 1 / 2: a.C / a2.C rounded up to 32, zero
                           // filled, so that the kernel needs no K-tail predicate (gamma/beta are padded alike)
 };
@@ -123,6 +131,9 @@ struct Op {
   GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf;
 };
 
+struct ChunkDesc { int a_off, w_off, gkc, flags; };
+struct PixHdr { int first, total, n1, p2; };
+
 // One executable plan: a straight-line op list over two arenas.
 struct Plan {
   int B = 0;
@@ -139,6 +150,7 @@ struct Plan {
   double flops_dense = 0;        // 2*MAC, dense convention (zero-padding taps counted)
   double flops_exec = 0;         // 2*MAC actually issued (padding taps skipped, channel padding included)
   double flops_dense_gemm = 0;   // the part of flops_dense computed by seg_gemm launches
+  int64_t ident_off = -1;        // params: 32 ones followed by 32 zeros (identity gamma/beta for chunks without GroupNorm)
   std::string error;
 };
 
@@ -171,6 +183,9 @@ bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const
 struct AttrDecCfg { int size_z = 256, att_size = 18; };
 std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& cfg);
 bool build_attrdec_plan(const AttrDecCfg& cfg, int B, int z_ld, const float* const* tensors, Plan* plan);
+
+// builds hdr/desc for every GEMM op and the identity gamma/beta block; called at the end of every build_*_plan
+void finalize_gemm_tables(Plan* plan);
 
 SBM_HD inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }

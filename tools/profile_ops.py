@@ -44,7 +44,7 @@ for i in range(n):
     print(f"{i:3d} {buf.value.decode()[:58]:58s} {us:8.1f} {fl[i] / 1e9:8.3f} {tf:7.1f}")
 if os.environ.get("SBM_STAMPS"):
     print("in-kernel cycle stamps (middle block, wave 0): prologue / loop / epilogue | wait issue compute | chunks grid")
-    st = (ctypes.c_uint64 * 8)()
+    st = (ctypes.c_uint64 * 16)()
     for i in range(n):
         L.sbm_debug_op_name(eng.h, i, buf, 256)
         if not buf.value.decode().startswith("0:"):
@@ -52,5 +52,5 @@ if os.environ.get("SBM_STAMPS"):
         _lib.check(L.sbm_debug_gemm_stamps(eng.h, x.data_ptr(), out.data_ptr(), i, st))
         v = list(st)
         print(f"{i:3d} {buf.value.decode()[:44]:44s} pro {v[0]:7d} loop {v[1]:8d} epi {v[2]:7d} | wait {v[3]:8d} issue {v[4]:7d} comp {v[5]:8d} | "
-              f"chunks {v[6]:3d} grid {v[7]:5d}  cyc/chunk {v[1] / max(v[6], 1):7.0f}")
+              f"chunks {v[6]:3d} grid {v[7]:5d}  cyc/chunk {v[5] / max(v[6], 1):6.0f} | prefill {v[8]:6d} gnload {v[9]:6d} gnred {v[10]:6d} setup {v[11]:5d}")
 print(f"total {tot:.1f} us; dense FLOP {eng.info['flops_dense'] / 1e9:.2f} G, exec FLOP {eng.info['flops_exec'] / 1e9:.2f} G")
