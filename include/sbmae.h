@@ -29,7 +29,8 @@ typedef struct sbm_model sbm_model;
 enum sbm_kind {
   SBM_UNET = 0,    /* unet_model.Unet (ConvNeXt score net)                 unet_model.py:189-323 */
   SBM_RESDEC = 1,  /* h_vae_model_copy.ResVAE/ResAE/ResVAEN/ResAEN.decoder  h_vae_model_copy.py:123-126,166-169,489-492,576-579 */
-  SBM_ATTRDEC = 2  /* h_vae_model.CelebAAttrNewBN[AE].decoder               h_vae_model.py:768-769,888-890 */
+  SBM_ATTRDEC = 2, /* h_vae_model.CelebAAttrNewBN[AE].decoder               h_vae_model.py:768-769,888-890 */
+  SBM_UNET_OA = 3  /* unet_openai.UNetModel (conditional CelebA score net)   unet_openai.py:361-575 */
 };
 
 /* Integer configuration vectors (`cfg`):
@@ -39,6 +40,9 @@ enum sbm_kind {
  *                enc_channel_list (4 ints each)..., dec_channel_list (4 ints each)...]
  *               = the constructor arguments of ResVAE (h_vae_model_copy.py:92)
  *   SBM_ATTRDEC [size_z, att_size]   (h_vae_model.py:713)
+ *   SBM_UNET_OA [in_channels, model_channels, out_channels, num_res_blocks, num_heads, z_dim, use_z, H, W,
+ *                n_mult, channel_mult..., n_attn, attention_resolutions...]  (unet_openai.py:383-401);
+ *               sbm_model_create's `in_pitch` selects the variant: 1 = forward(x, t, z=z), 0 = forward(x, t)
  */
 
 const char* sbm_last_error(void);
@@ -69,6 +73,13 @@ int sbm_model_info(const sbm_model* m, double* info);
  *   SBM_RESDEC:  in = z rows (B x size_z, pitch in_pitch), t = NULL, out (B,img_ch,S,S)  == .decoder(z)
  *   SBM_ATTRDEC: in = z rows, out (B, att_size)                                 == .decoder(z)          */
 int sbm_model_forward(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, void* stream);
+
+/* UNetModel.forward(x, timesteps, z=z_cond) (unet_openai.py:538): aux_dev = z (B, z_dim) for a model built with in_pitch=1. */
+int sbm_model_forward_aux(sbm_model* m, const float* in_dev, const float* t_dev, const float* aux_dev, float* out_dev, void* stream);
+
+/* Conditioning vector used by subsequent sbm_sampler_run calls on a with_z model: score_fn(x, t) == UNetModel(x, t, z=z_cond)
+ * (the semantics train_lat_celebhq_unet_cont2_cond.py:225-226 intends; as shipped those calls raise TypeError -- SURVEY D8). */
+int sbm_model_set_aux(sbm_model* m, const float* aux_dev);
 
 /* Per-kernel timing of one forward with HIP events around every launch (eager, `reps` repetitions
  * after one warm-up).  ms_by_kind[k] / launches_by_kind[k] for k = plan op kind (0 = seg_gemm,

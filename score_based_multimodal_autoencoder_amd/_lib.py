@@ -14,11 +14,12 @@ LIB_PATH = os.path.join(CSRC, "libsbmae_hip.so")
 SOURCES = ["plan.cpp", "kernels.hip", "sampler.hip", "api.hip"]
 HEADERS = ["plan.h", "device.h", os.path.join("..", "..", "include", "sbmae.h")]
 
-SBM_UNET, SBM_RESDEC, SBM_ATTRDEC = 0, 1, 2
-OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "nchw_to_pbc", "bilinear"]
+SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA = 0, 1, 2, 3
+OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "nchw_to_pbc", "bilinear", "gn_final", "gn32",
+                 "attn_qkv"]
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
-           "sbm_model_info", "sbm_model_forward", "sbm_model_profile", "sbm_em_step", "sbm_langevin_step",
+           "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_em_step", "sbm_langevin_step",
            "sbm_fill_normal", "sbm_sampler_run", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps"]
 
@@ -76,6 +77,8 @@ def lib():
         L.sbm_model_destroy.restype = None
         L.sbm_model_info.argtypes = [vp, ctypes.POINTER(dbl)]
         L.sbm_model_forward.argtypes = [vp, vp, vp, vp, vp]
+        L.sbm_model_forward_aux.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.sbm_model_set_aux.argtypes = [vp, vp]
         L.sbm_model_profile.argtypes = [vp, vp, vp, vp, i, ctypes.POINTER(dbl), ip, i]
         L.sbm_em_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, vp]
         L.sbm_langevin_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
@@ -118,6 +121,12 @@ def specs(kind, cfg):
 def unet_cfg_ints(dim, channels, dim_mults, H, W, init_dim=None, out_dim=None, with_time_emb=True, convnext_mult=2):
     return [dim, channels, init_dim or 0, out_dim or 0, int(bool(with_time_emb)), convnext_mult, H, W, len(dim_mults)] + \
         [int(m) for m in dim_mults]
+
+
+def unet_oa_cfg_ints(in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, channel_mult, H, W,
+                     num_heads=1, z_dim=0, use_z=False):
+    return [in_channels, model_channels, out_channels, num_res_blocks, num_heads, z_dim or 0, int(bool(use_z)), H, W,
+            len(channel_mult)] + [int(m) for m in channel_mult] + [len(attention_resolutions)] + [int(a) for a in attention_resolutions]
 
 
 def resdec_cfg_ints(variant, enc, dec, size_in, size_z, img_ch):
@@ -174,6 +183,11 @@ class Engine:
     def forward(self, x, t, out):
         check(lib().sbm_model_forward(self.h, x.data_ptr(), t.data_ptr() if t is not None else None, out.data_ptr(),
                                       stream_ptr()))
+        return out
+
+    def forward_aux(self, x, t, aux, out):
+        check(lib().sbm_model_forward_aux(self.h, x.data_ptr(), t.data_ptr(), aux.data_ptr() if aux is not None else None,
+                                          out.data_ptr(), stream_ptr()))
         return out
 
     def profile(self, x, t, out, reps=5):

@@ -183,3 +183,108 @@ def attr_entries(size_z=64, att_size=18, ae=False):
 
 def attr_state_shapes(size_z=64, att_size=18, ae=False):
     return dict(attr_entries(size_z, att_size, ae))
+
+
+# --------------------------------------------------------------------------------------------------
+# unet_openai.UNetModel (reference unet_openai.py:361-575), the conditional CelebA score net (config 5)
+# --------------------------------------------------------------------------------------------------
+def unet_openai_structure(in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions=(),
+                          channel_mult=(1, 2, 4, 8)):
+    """Block list mirroring UNetModel.__init__: returns (input_blocks, middle, output_blocks) where every block is
+    a list of layers: ("conv", cin, cout) | ("res", cin, cout) | ("attn", ch) | ("down", ch) | ("up", ch)."""
+    inputs = [[("conv", in_channels, model_channels)]]
+    chans = [model_channels]
+    ch, ds = model_channels, 1
+    for level, mult in enumerate(channel_mult):
+        for _ in range(num_res_blocks):
+            layers = [("res", ch, mult * model_channels)]
+            ch = mult * model_channels
+            if ds in attention_resolutions:
+                layers.append(("attn", ch))
+            inputs.append(layers)
+            chans.append(ch)
+        if level != len(channel_mult) - 1:
+            inputs.append([("down", ch)])
+            chans.append(ch)
+            ds *= 2
+    middle = [("res", ch, ch), ("attn", ch), ("res", ch, ch)]
+    outputs = []
+    for level, mult in list(enumerate(channel_mult))[::-1]:
+        for i in range(num_res_blocks + 1):
+            layers = [("res", ch + chans.pop(), model_channels * mult)]
+            ch = model_channels * mult
+            if ds in attention_resolutions:
+                layers.append(("attn", ch))
+            if level and i == num_res_blocks:
+                layers.append(("up", ch))
+                ds //= 2
+            outputs.append(layers)
+    return inputs, middle, outputs
+
+
+def _oa_layer(pre, layer, emb):
+    kind = layer[0]
+    if kind == "conv":
+        yield pre + "weight", (layer[2], layer[1], 3, 3)
+        yield pre + "bias", (layer[2],)
+    elif kind == "res":
+        _, cin, cout = layer
+        yield pre + "in_layers.0.weight", (cin,)
+        yield pre + "in_layers.0.bias", (cin,)
+        yield pre + "in_layers.2.weight", (cout, cin, 3, 3)
+        yield pre + "in_layers.2.bias", (cout,)
+        yield pre + "emb_layers.1.weight", (cout, emb)
+        yield pre + "emb_layers.1.bias", (cout,)
+        yield pre + "out_layers.0.weight", (cout,)
+        yield pre + "out_layers.0.bias", (cout,)
+        yield pre + "out_layers.3.weight", (cout, cout, 3, 3)
+        yield pre + "out_layers.3.bias", (cout,)
+        if cin != cout:
+            yield pre + "skip_connection.weight", (cout, cin, 1, 1)
+            yield pre + "skip_connection.bias", (cout,)
+    elif kind == "attn":
+        ch = layer[1]
+        yield pre + "norm.weight", (ch,)
+        yield pre + "norm.bias", (ch,)
+        yield pre + "qkv.weight", (3 * ch, ch, 1)
+        yield pre + "qkv.bias", (3 * ch,)
+        yield pre + "proj_out.weight", (ch, ch, 1)
+        yield pre + "proj_out.bias", (ch,)
+    elif kind == "down":
+        yield pre + "op.weight", (layer[1], layer[1], 3, 3)
+        yield pre + "op.bias", (layer[1],)
+    elif kind == "up":
+        yield pre + "conv.weight", (layer[1], layer[1], 3, 3)
+        yield pre + "conv.bias", (layer[1],)
+
+
+def unet_openai_entries(in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions=(),
+                        channel_mult=(1, 2, 4, 8), z_dim=None, use_z=False):
+    emb = model_channels * 4
+    yield "time_embed.0.weight", (emb, model_channels)
+    yield "time_embed.0.bias", (emb,)
+    yield "time_embed.2.weight", (emb, emb)
+    yield "time_embed.2.bias", (emb,)
+    if use_z:
+        yield "proj.0.weight", (emb, z_dim)
+        yield "proj.0.bias", (emb,)
+        yield "proj.2.weight", (emb, emb)
+        yield "proj.2.bias", (emb,)
+    inputs, middle, outputs = unet_openai_structure(in_channels, model_channels, out_channels, num_res_blocks,
+                                                    attention_resolutions, channel_mult)
+    for bi, layers in enumerate(inputs):
+        for li, layer in enumerate(layers):
+            yield from _oa_layer(f"input_blocks.{bi}.{li}.", layer, emb)
+    for li, layer in enumerate(middle):
+        yield from _oa_layer(f"middle_block.{li}.", layer, emb)
+    for bi, layers in enumerate(outputs):
+        for li, layer in enumerate(layers):
+            yield from _oa_layer(f"output_blocks.{bi}.{li}.", layer, emb)
+    yield "out.0.weight", (model_channels,)
+    yield "out.0.bias", (model_channels,)
+    yield "out.2.weight", (out_channels, model_channels, 3, 3)
+    yield "out.2.bias", (out_channels,)
+
+
+def unet_openai_state_shapes(**kw):
+    return dict(unet_openai_entries(**kw))

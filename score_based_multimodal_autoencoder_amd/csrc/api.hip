@@ -25,6 +25,7 @@ struct sbm_model {
   float* d_params = nullptr;
   float* d_ws = nullptr;
   GemmCold* d_cold = nullptr;    // one per op (only the GEMM entries are meaningful)
+  const float* aux_persistent = nullptr;   // z_cond used by sbm_sampler_run (sbm_model_set_aux)
   DevPlan dp;
   // sampler scratch (score nets only)
   float* d_score = nullptr;
@@ -47,7 +48,16 @@ static ResDecCfg resdec_cfg_from_ints(const int* c) {
   for (int i = 0; i < r.n_dec; ++i) for (int j = 0; j < 4; ++j) r.dec[i][j] = *e++;
   return r;
 }
+static UnetOACfg unet_oa_cfg_from_ints(const int* c) {
+  UnetOACfg u; u.in_channels = c[0]; u.model_channels = c[1]; u.out_channels = c[2]; u.num_res_blocks = c[3]; u.num_heads = c[4];
+  u.z_dim = c[5]; u.use_z = c[6]; u.H = c[7]; u.W = c[8]; u.n_mult = c[9] < 8 ? c[9] : 8;
+  for (int i = 0; i < u.n_mult; ++i) u.channel_mult[i] = c[10 + i];
+  u.n_attn = c[10 + u.n_mult] < 8 ? c[10 + u.n_mult] : 8;
+  for (int i = 0; i < u.n_attn; ++i) u.attn_res[i] = c[11 + u.n_mult + i];
+  return u;
+}
 static std::vector<TensorSpec> specs_of(int kind, const int* cfg) {
+  if (kind == SBM_UNET_OA) return unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg));
   if (kind == SBM_UNET) return unet_tensor_specs(unet_cfg_from_ints(cfg));
   if (kind == SBM_RESDEC) return resdec_tensor_specs(resdec_cfg_from_ints(cfg));
   if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; return attrdec_tensor_specs(a); }
@@ -108,6 +118,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   if (kind == SBM_UNET) ok = build_unet_plan(unet_cfg_from_ints(cfg), batch, host_tensors, &m->plan);
   else if (kind == SBM_RESDEC) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), batch, in_pitch, host_tensors, &m->plan);
   else if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, batch, in_pitch, host_tensors, &m->plan); }
+  else if (kind == SBM_UNET_OA) ok = build_unet_oa_plan(unet_oa_cfg_from_ints(cfg), batch, in_pitch, host_tensors, &m->plan);
   else m->plan.error = "unknown model kind";
   if (!ok) { std::string e = m->plan.error; delete m; return fail("sbm_model_create: " + e); }
   const size_t pbytes = m->plan.params.size() * sizeof(float), wbytes = (size_t)m->plan.ws_floats * sizeof(float);
@@ -130,7 +141,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
     }
     if ((e = hipMemcpy(m->d_cold, cold.data(), sizeof(GemmCold) * nops, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(cold args)", e); }
   }
-  if (kind == SBM_UNET) {
+  if (kind == SBM_UNET || kind == SBM_UNET_OA) {
     const size_t sbytes = (size_t)batch * m->plan.out_C * m->plan.out_H * m->plan.out_W * sizeof(float);
     if ((e = hipMalloc(&m->d_score, sbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(score)", e); }
     if ((e = hipMalloc(&m->d_norms, (size_t)batch * 2 * sizeof(float))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(norms)", e); }
@@ -151,6 +162,22 @@ int sbm_model_info(const sbm_model* m, double* info) {
   info[0] = (double)m->plan.ops.size(); info[1] = (double)m->plan.ws_floats * 4; info[2] = 0;
   info[3] = m->plan.flops_dense; info[4] = m->plan.flops_exec; info[5] = ng; info[6] = m->plan.B; info[7] = m->plan.flops_dense_gemm;
   return 0;
+}
+
+int sbm_model_set_aux(sbm_model* m, const float* aux_dev) {
+  if (!m) return fail("sbm_model_set_aux: bad arguments");
+  if (m->plan.aux_off < 0 && aux_dev) return fail("sbm_model_set_aux: this model variant takes no auxiliary input");
+  m->aux_persistent = aux_dev;
+  return 0;
+}
+
+int sbm_model_forward_aux(sbm_model* m, const float* in_dev, const float* t_dev, const float* aux_dev, float* out_dev, void* stream) {
+  if (!m || !in_dev || !out_dev) return fail("sbm_model_forward_aux: bad arguments");
+  if ((m->plan.aux_off >= 0) != (aux_dev != nullptr)) return fail("sbm_model_forward_aux: this model variant was built with_z / without z; pass z accordingly");
+  m->dp.aux = aux_dev;
+  const int rc = sbm_model_forward(m, in_dev, t_dev, out_dev, stream);
+  m->dp.aux = nullptr;
+  return rc;
 }
 
 int sbm_model_forward(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, void* stream) {
@@ -346,7 +373,9 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
 
 int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const float* timesteps, const float* alphas, const float* noise,
                     float* x_inout, float* x_mean_out, int first_step, int n_run, float* elapsed_ms, void* stream) {
-  if (!m || m->kind != SBM_UNET || !sde || !cfg || !timesteps || !x_inout || !x_mean_out) return fail("sbm_sampler_run: bad arguments");
+  if (!m || (m->kind != SBM_UNET && m->kind != SBM_UNET_OA) || !sde || !cfg || !timesteps || !x_inout || !x_mean_out) return fail("sbm_sampler_run: bad arguments");
+  if (m->plan.aux_off >= 0 && !m->aux_persistent) return fail("sbm_sampler_run: the score net was built with z conditioning; call sbm_model_set_aux first");
+  m->dp.aux = m->aux_persistent;
   if (!m->plan.needs_time) return fail("sbm_sampler_run: the score net has no time embedding");
   if (first_step < 0 || n_run < 0 || first_step + n_run > sde->N) return fail("sbm_sampler_run: step range outside [0, N)");
   if (cfg->pc && cfg->n_steps <= 0) return fail("sbm_sampler_run: n_steps must be positive when pc is set");

@@ -36,6 +36,7 @@ struct DevPlan {
   const float* prm = nullptr;   // device params arena
   float* ws = nullptr;          // device workspace arena
   std::vector<GemmHot> hot;     // per op (valid for OP_GEMM)
+  const float* aux = nullptr;   // per-call auxiliary input (UNetModel z), copied into ws[plan.aux_off] by run_plan
 };
 const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, float* ws, const GemmCold* cold_dev, GemmHot* hot, GemmCold* cold);
 

@@ -196,7 +196,8 @@ static void run_bilinear(const BilinearOp& o, float* ws) {
   }
 }
 
-void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const float* t, float* out, int n_ops = 1 << 30) {
+void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const float* t, float* out, int n_ops = 1 << 30, const float* aux = nullptr) {
+  if (plan.aux_off >= 0 && aux) std::memcpy(&ws[plan.aux_off], aux, sizeof(float) * plan.B * plan.aux_C);
   const float* prm = plan.params.data();
   if (plan.time_off >= 0 && t) std::memcpy(&ws[plan.time_off], t, sizeof(float) * plan.B);
   int done = 0;
@@ -212,8 +213,8 @@ void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const 
         const SinusOp& s = op.si; const int half = s.dim / 2;
         for (int b = 0; b < s.B; ++b) for (int j = 0; j < half; ++j) {
           float arg = ws[plan.time_off + b] * prm[s.freq_off + j];
-          ws[s.out_off + (int64_t)b * s.ld + j] = (float)std::sin((double)arg);
-          ws[s.out_off + (int64_t)b * s.ld + half + j] = (float)std::cos((double)arg);
+          ws[s.out_off + (int64_t)b * s.ld + (s.cos_first ? half : 0) + j] = (float)std::sin((double)arg);
+          ws[s.out_off + (int64_t)b * s.ld + (s.cos_first ? 0 : half) + j] = (float)std::cos((double)arg);
         }
         for (int b = 0; b < s.B; ++b) for (int j = 2 * half; j < s.ld; ++j) ws[s.out_off + (int64_t)b * s.ld + j] = 0.f;
       } break;
@@ -227,6 +228,39 @@ void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const 
         }
       } break;
       case OP_BILINEAR: run_bilinear(op.bl, ws.data()); break;
+      case OP_GN32: {
+        const Gn32Op& o = op.gn; const int P = o.in.H * o.in.W, C = o.in.C, cg = C / o.groups;
+        for (int b = 0; b < o.B; ++b) for (int g = 0; g < o.groups; ++g) {
+          double s = 0, q = 0;
+          for (int p = 0; p < P; ++p) for (int c = g * cg; c < (g + 1) * cg; ++c) { const double v = ws[o.in.off + ((int64_t)p * o.B + b) * o.in.ld + c]; s += v; q += v * v; }
+          const double mean = s / (P * cg); double var = q / (P * cg) - mean * mean; if (var < 0) var = 0;
+          const double rstd = 1.0 / std::sqrt(var + 1e-5);
+          for (int p = 0; p < P; ++p) for (int c = g * cg; c < (g + 1) * cg; ++c) {
+            float y = (float)(((double)ws[o.in.off + ((int64_t)p * o.B + b) * o.in.ld + c] - mean) * rstd) * prm[o.gamma_off + c] + prm[o.beta_off + c];
+            if (o.silu) y = act_apply(ACT_SILU, y);
+            ws[o.out.off + ((int64_t)p * o.B + b) * o.out.ld + c] = y;
+          }
+        }
+      } break;
+      case OP_ATTN_QKV: {
+        const AttnQkvOp& o = op.aq; const int T = o.qkv.H * o.qkv.W, ch = o.chh;
+        std::vector<double> w((size_t)T * T);
+        for (int b = 0; b < o.B; ++b) for (int h = 0; h < o.heads; ++h) {
+          auto Q = [&](int c, int t) { return (double)ws[o.qkv.off + ((int64_t)t * o.B + b) * o.qkv.ld + h * 3 * ch + c]; };
+          auto K = [&](int c, int t) { return (double)ws[o.qkv.off + ((int64_t)t * o.B + b) * o.qkv.ld + h * 3 * ch + ch + c]; };
+          auto V = [&](int c, int t) { return (double)ws[o.qkv.off + ((int64_t)t * o.B + b) * o.qkv.ld + h * 3 * ch + 2 * ch + c]; };
+          for (int t = 0; t < T; ++t) {
+            double m = -1e300;
+            for (int u = 0; u < T; ++u) { double a = 0; for (int c = 0; c < ch; ++c) a += Q(c, t) * o.scale * K(c, u) * o.scale; w[(size_t)t * T + u] = a; m = std::max(m, a); }
+            double z = 0; for (int u = 0; u < T; ++u) { w[(size_t)t * T + u] = std::exp(w[(size_t)t * T + u] - m); z += w[(size_t)t * T + u]; }
+            for (int u = 0; u < T; ++u) w[(size_t)t * T + u] /= z;
+          }
+          for (int t = 0; t < T; ++t) for (int c = 0; c < ch; ++c) {
+            double a = 0; for (int u = 0; u < T; ++u) a += w[(size_t)t * T + u] * V(c, u);
+            ws[o.out.off + ((int64_t)t * o.B + b) * o.out.ld + h * ch + c] = (float)a;
+          }
+        }
+      } break;
       default: break;
     }
   }
@@ -249,6 +283,15 @@ static UnetCfg unet_cfg_from_ints(const int* c) {
   for (int i = 0; i < u.n_mults && i < 8; ++i) u.dim_mults[i] = c[9 + i];
   return u;
 }
+static UnetOACfg unet_oa_cfg_from_ints(const int* c) {
+  // [in_ch, model_ch, out_ch, num_res_blocks, num_heads, z_dim, use_z, H, W, n_mult, mults..., n_attn, attn_res...]
+  UnetOACfg u; u.in_channels = c[0]; u.model_channels = c[1]; u.out_channels = c[2]; u.num_res_blocks = c[3]; u.num_heads = c[4];
+  u.z_dim = c[5]; u.use_z = c[6]; u.H = c[7]; u.W = c[8]; u.n_mult = c[9] < 8 ? c[9] : 8;
+  for (int i = 0; i < u.n_mult; ++i) u.channel_mult[i] = c[10 + i];
+  u.n_attn = c[10 + u.n_mult] < 8 ? c[10 + u.n_mult] : 8;
+  for (int i = 0; i < u.n_attn; ++i) u.attn_res[i] = c[11 + u.n_mult + i];
+  return u;
+}
 static ResDecCfg resdec_cfg_from_ints(const int* c) {
   // [variant, size_in, size_z, img_ch, n_enc, n_dec, enc(4*n_enc)..., dec(4*n_dec)...]
   ResDecCfg r; r.variant = c[0]; r.size_in = c[1]; r.size_z = c[2]; r.img_ch = c[3]; r.n_enc = c[4]; r.n_dec = c[5];
@@ -268,6 +311,7 @@ void* sbmref_build(int kind, const int* cfg, int B, int z_ld, const float* const
   if (kind == 0) ok = build_unet_plan(unet_cfg_from_ints(cfg), B, tensors, &h->plan);
   else if (kind == 1) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);
   else if (kind == 2) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, B, z_ld, tensors, &h->plan); }
+  else if (kind == 3) ok = build_unet_oa_plan(unet_oa_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);
   if (!ok) { g_err = h->plan.error.empty() ? "unknown plan kind" : h->plan.error; delete h; return nullptr; }
   h->ws.assign((size_t)h->plan.ws_floats, std::nanf(""));      // poison: every read must be preceded by a write
   return h;
@@ -276,6 +320,7 @@ void* sbmref_build(int kind, const int* cfg, int B, int z_ld, const float* const
 int sbmref_num_specs(int kind, const int* cfg) {
   if (kind == 0) return (int)unet_tensor_specs(unet_cfg_from_ints(cfg)).size();
   if (kind == 1) return (int)resdec_tensor_specs(resdec_cfg_from_ints(cfg)).size();
+  if (kind == 3) return (int)unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg)).size();
   AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1];
   return (int)attrdec_tensor_specs(a).size();
 }
@@ -284,6 +329,7 @@ long sbmref_spec(int kind, const int* cfg, int i, char* name, int cap) {
   std::vector<TensorSpec> s;
   if (kind == 0) s = unet_tensor_specs(unet_cfg_from_ints(cfg));
   else if (kind == 1) s = resdec_tensor_specs(resdec_cfg_from_ints(cfg));
+  else if (kind == 3) s = unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg));
   else { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; s = attrdec_tensor_specs(a); }
   if (i < 0 || i >= (int)s.size()) return -1;
   std::strncpy(name, s[i].name.c_str(), cap - 1); name[cap - 1] = 0;
@@ -304,6 +350,11 @@ void sbmref_info(void* hv, double* o) {
   o[3] = h->plan.flops_dense; o[4] = h->plan.flops_exec; o[5] = ng;
 }
 
+int sbmref_run_aux(void* hv, const float* in, const float* t, const float* aux, float* out) {
+  RefHandle* h = (RefHandle*)hv;
+  interpret(h->plan, h->ws, in, t, out, 1 << 30, aux);
+  return 0;
+}
 int sbmref_run_partial(void* hv, const float* in, const float* t, float* out, int n_ops) {
   RefHandle* h = (RefHandle*)hv;
   interpret(h->plan, h->ws, in, t, out, n_ops);

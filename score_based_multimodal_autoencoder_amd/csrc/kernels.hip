@@ -615,14 +615,129 @@ __global__ __launch_bounds__(256) void gn_res_kernel(const GnResArgs g) {
 // ------------------------------------------------------------------------------------------------
 // small boundary kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void sinus_kernel(const float* t, const float* freq, float* out, int B, int dim, int ld) {
+__global__ void sinus_kernel(const float* t, const float* freq, float* out, int B, int dim, int ld, int cos_first) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * ld) return;
   const int b = idx / ld, j = idx - b * ld, half = dim / 2;
   float v = 0.f;
-  if (j < half) v = sinf(t[b] * freq[j]);
-  else if (j < 2 * half) v = cosf(t[b] * freq[j - half]);
+  if (j < 2 * half) {
+    const bool first = j < half;
+    const float a = t[b] * freq[first ? j : j - half];
+    v = (first != (cos_first != 0)) ? sinf(a) : cosf(a);     // unet_model: [sin, cos]; unet_openai: [cos, sin]
+  }
   out[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(G, C) (+ SiLU), materialised (unet_openai normalization()): one workgroup per sample; every thread
+// always touches the same channel quads, hence the same groups, so the group sums reduce in a fixed order.
+// ------------------------------------------------------------------------------------------------
+struct Gn32Args { const float* in; float* out; const float* gamma; const float* beta; int B, P, C, ldi, ldo, groups, silu; };
+
+__global__ __launch_bounds__(256) void gn32_kernel(const Gn32Args a) {
+  __shared__ float2 part[256 * 2];
+  __shared__ float2 stat[64];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int c4n = a.C / 4, cg = a.C / a.groups;
+  const int npt = (c4n + 255) / 256;                        // channel quads per thread (<= 2 for C <= 2048)
+  const int rows_per_iter = c4n >= 256 ? 1 : 256 / c4n;     // pixels covered per sweep when C/4 < 256
+  const int q0 = c4n >= 256 ? tid : tid % c4n, prow = c4n >= 256 ? 0 : tid / c4n;
+  const bool active = c4n >= 256 || tid < rows_per_iter * c4n;
+  for (int k = 0; k < 2; ++k) {
+    float s = 0.f, q = 0.f;
+    const int c4 = q0 + k * 256;
+    if (k < npt && c4 < c4n && active)
+      for (int p = prow; p < a.P; p += rows_per_iter) {
+        const float4 v = *reinterpret_cast<const float4*>(a.in + ((long long)p * a.B + b) * a.ldi + c4 * 4);
+        s += (v.x + v.y) + (v.z + v.w); q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    part[k * 256 + tid] = make_float2(s, q);
+  }
+  __syncthreads();
+  if (tid < a.groups) {
+    // entries of group g: threads whose quad lies in [g*cg/4, (g+1)*cg/4)
+    double s = 0.0, q = 0.0;
+    const int lo = tid * cg / 4, hi = (tid + 1) * cg / 4;
+    for (int k = 0; k < npt; ++k)
+      for (int c4 = lo; c4 < hi; ++c4) {
+        if (c4 < k * 256 || c4 >= (k + 1) * 256) continue;
+        const int qq = c4 - k * 256;
+        if (c4n >= 256) { const float2 v = part[k * 256 + qq]; s += v.x; q += v.y; }
+        else for (int r = 0; r < rows_per_iter; ++r) { const float2 v = part[r * c4n + qq]; s += v.x; q += v.y; }
+      }
+    const double n = (double)a.P * cg, mean = s / n;
+    double var = q / n - mean * mean; var = var < 0.0 ? 0.0 : var;
+    stat[tid] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+  }
+  __syncthreads();
+  for (int k = 0; k < npt; ++k) {
+    const int c4 = q0 + k * 256;
+    if (c4 >= c4n || !active) continue;
+    const float2 st = stat[(c4 * 4) / cg];
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c4 * 4), be = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
+    for (int p = prow; p < a.P; p += rows_per_iter) {
+      float4 v = *reinterpret_cast<const float4*>(a.in + ((long long)p * a.B + b) * a.ldi + c4 * 4);
+      v.x = ((v.x - st.x) * st.y) * ga.x + be.x; v.y = ((v.y - st.x) * st.y) * ga.y + be.y;
+      v.z = ((v.z - st.x) * st.y) * ga.z + be.z; v.w = ((v.w - st.x) * st.y) * ga.w + be.w;
+      if (a.silu) { v.x = act_apply(ACT_SILU, v.x); v.y = act_apply(ACT_SILU, v.y); v.z = act_apply(ACT_SILU, v.z); v.w = act_apply(ACT_SILU, v.w); }
+      *reinterpret_cast<float4*>(a.out + ((long long)p * a.B + b) * a.ldo + c4 * 4) = v;
+    }
+  }
+}
+
+// groups narrower than 4 channels (toy widths only): one thread per (sample, group), serial over its elements
+__global__ void gn32_small_kernel(const Gn32Args a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.B * a.groups) return;
+  const int b = idx / a.groups, g = idx - b * a.groups, cg = a.C / a.groups;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < a.P; ++p) for (int c = g * cg; c < (g + 1) * cg; ++c) { const double v = a.in[((long long)p * a.B + b) * a.ldi + c]; s += v; q += v * v; }
+  const double n = (double)a.P * cg, mean = s / n;
+  double var = q / n - mean * mean; var = var < 0.0 ? 0.0 : var;
+  const float m = (float)mean, r = (float)(1.0 / sqrt(var + 1e-5));
+  for (int p = 0; p < a.P; ++p) for (int c = g * cg; c < (g + 1) * cg; ++c) {
+    float y = ((a.in[((long long)p * a.B + b) * a.ldi + c] - m) * r) * a.gamma[c] + a.beta[c];
+    if (a.silu) y = act_apply(ACT_SILU, y);
+    a.out[((long long)p * a.B + b) * a.ldo + c] = y;
+  }
+}
+
+// unet_openai QKVAttention core (unet_openai.py:346-358): one workgroup per (sample, head), T <= 64 tokens.
+struct AttnQkvArgs { const float* qkv; float* out; int B, T, ldq, ldo, heads, chh; float scale; };
+
+__global__ __launch_bounds__(256) void attn_qkv_kernel(const AttnQkvArgs a) {
+  __shared__ float w[64 * 64];
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+  const float* base = a.qkv + (long long)b * a.ldq + h * 3 * a.chh;
+  const long long ts = (long long)a.B * a.ldq;
+  const float s2 = a.scale * a.scale;
+  for (int pair = 0; pair < a.T * a.T; ++pair) {
+    const int t = pair / a.T, u = pair - t * a.T;
+    float acc = 0.f;
+    for (int c = tid; c < a.chh; c += 256) acc = fmaf(base[t * ts + c], base[u * ts + a.chh + c], acc);
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) w[pair] = red[0] * s2;
+    __syncthreads();
+  }
+  if (tid < a.T) {
+    float m = -INFINITY;
+    for (int u = 0; u < a.T; ++u) m = fmaxf(m, w[tid * a.T + u]);
+    float z = 0.f;
+    for (int u = 0; u < a.T; ++u) { const float e = expf(w[tid * a.T + u] - m); w[tid * a.T + u] = e; z += e; }
+    const float inv = 1.0f / z;
+    for (int u = 0; u < a.T; ++u) w[tid * a.T + u] *= inv;
+  }
+  __syncthreads();
+  for (int c = tid; c < a.chh; c += 256)
+    for (int t = 0; t < a.T; ++t) {
+      float acc = 0.f;
+      for (int u = 0; u < a.T; ++u) acc = fmaf(w[t * a.T + u], base[u * ts + 2 * a.chh + c], acc);
+      a.out[((long long)t * a.B + b) * a.ldo + h * a.chh + c] = acc;
+    }
 }
 
 __global__ void nchw_to_pbc_kernel(const float* in, float* out, int B, int C, int Hn, int Wn, int pad_y, int pad_x, int Ho, int Wo, int ld, int Cv) {
@@ -740,7 +855,7 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
     } break;
     case OP_SINUS: {
       const SinusOp& o = op.si; const int n = o.B * o.ld;
-      hipLaunchKernelGGL(sinus_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ws + plan.time_off, prm + o.freq_off, ws + o.out_off, o.B, o.dim, o.ld);
+      hipLaunchKernelGGL(sinus_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ws + plan.time_off, prm + o.freq_off, ws + o.out_off, o.B, o.dim, o.ld, o.cos_first);
     } break;
     case OP_NCHW_TO_PBC: {
       const CvtOp& o = op.cv; const long long n = (long long)o.out.H * o.out.W * o.B * o.out.C;
@@ -752,6 +867,20 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       const long long n = (long long)a.Ho * a.Wo * a.B * (a.C / 4);
       hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     } break;
+    case OP_GN32: {
+      const Gn32Op& o = op.gn; Gn32Args a{};
+      a.in = ws + o.in.off; a.out = ws + o.out.off; a.gamma = prm + o.gamma_off; a.beta = prm + o.beta_off;
+      a.B = o.B; a.P = o.in.H * o.in.W; a.C = o.in.C; a.ldi = o.in.ld; a.ldo = o.out.ld; a.groups = o.groups; a.silu = o.silu;
+      if (o.in.C % o.groups || o.in.C > 2048 || o.groups > 64) return "gn32: C must be a multiple of the group count and <= 2048";
+      if (o.in.C % (4 * o.groups)) hipLaunchKernelGGL(gn32_small_kernel, dim3(ceil_div(o.B * o.groups, 256)), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(gn32_kernel, dim3(o.B), dim3(256), 0, st, a);
+    } break;
+    case OP_ATTN_QKV: {
+      const AttnQkvOp& o = op.aq; AttnQkvArgs a{};
+      a.qkv = ws + o.qkv.off; a.out = ws + o.out.off; a.B = o.B; a.T = o.qkv.H * o.qkv.W; a.ldq = o.qkv.ld; a.ldo = o.out.ld; a.heads = o.heads; a.chh = o.chh; a.scale = o.scale;
+      if (a.T > 64) return "attention: more than 64 positions";
+      hipLaunchKernelGGL(attn_qkv_kernel, dim3(o.B * o.heads), dim3(256), 0, st, a);
+    } break;
     default: return "unknown op";
   }
   return nullptr;
@@ -761,6 +890,8 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
   const Plan& plan = *dp.plan;
   if (plan.time_off >= 0 && t_dev && t_dev != dp.ws + plan.time_off)
     if (hipMemcpyAsync(dp.ws + plan.time_off, t_dev, sizeof(float) * plan.B, hipMemcpyDeviceToDevice, st) != hipSuccess) return "time copy failed";
+  if (plan.aux_off >= 0 && dp.aux)
+    if (hipMemcpyAsync(dp.ws + plan.aux_off, dp.aux, sizeof(float) * plan.B * plan.aux_C, hipMemcpyDeviceToDevice, st) != hipSuccess) return "aux copy failed";
   for (int i = 0; i < (int)plan.ops.size(); ++i) {
     const char* e = launch_op(dp, i, ext_in, ext_out, st);
     if (e) return e;

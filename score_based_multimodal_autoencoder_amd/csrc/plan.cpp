@@ -718,6 +718,284 @@ void finalize_gemm_tables(Plan* plan) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// unet_openai.UNetModel
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct OALayer { int kind; int cin; int cout; };     // 0 conv, 1 res, 2 attn, 3 down, 4 up
+struct OAStruct { std::vector<std::vector<OALayer>> inputs, outputs; std::vector<OALayer> middle; std::vector<int> chans; };
+
+OAStruct oa_structure(const UnetOACfg& c) {
+  OAStruct S;
+  auto in_attn = [&](int ds) { for (int i = 0; i < c.n_attn; ++i) if (c.attn_res[i] == ds) return true; return false; };
+  const int mc = c.model_channels;
+  S.inputs.push_back({{0, c.in_channels, mc}});
+  std::vector<int> chans{mc};
+  int ch = mc, ds = 1;
+  for (int level = 0; level < c.n_mult; ++level) {
+    const int mult = c.channel_mult[level];
+    for (int r = 0; r < c.num_res_blocks; ++r) {
+      std::vector<OALayer> L{{1, ch, mult * mc}};
+      ch = mult * mc;
+      if (in_attn(ds)) L.push_back({2, ch, ch});
+      S.inputs.push_back(L); chans.push_back(ch);
+    }
+    if (level != c.n_mult - 1) { S.inputs.push_back({{3, ch, ch}}); chans.push_back(ch); ds *= 2; }
+  }
+  S.chans = chans;
+  S.middle = {{1, ch, ch}, {2, ch, ch}, {1, ch, ch}};
+  for (int level = c.n_mult - 1; level >= 0; --level) {
+    const int mult = c.channel_mult[level];
+    for (int i = 0; i <= c.num_res_blocks; ++i) {
+      const int skip = chans.back(); chans.pop_back();
+      std::vector<OALayer> L{{1, ch + skip, mc * mult}};
+      ch = mc * mult;
+      if (in_attn(ds)) L.push_back({2, ch, ch});
+      if (level && i == c.num_res_blocks) { L.push_back({4, ch, ch}); ds /= 2; }
+      S.outputs.push_back(L);
+    }
+  }
+  return S;
+}
+
+void oa_layer_specs(SpecList& L, const std::string& pre, const OALayer& l, int emb) {
+  if (l.kind == 0) { L.add(pre + "weight", {l.cout, l.cin, 3, 3}); L.add(pre + "bias", {l.cout}); }
+  else if (l.kind == 1) {
+    L.add(pre + "in_layers.0.weight", {l.cin}); L.add(pre + "in_layers.0.bias", {l.cin});
+    L.add(pre + "in_layers.2.weight", {l.cout, l.cin, 3, 3}); L.add(pre + "in_layers.2.bias", {l.cout});
+    L.add(pre + "emb_layers.1.weight", {l.cout, emb}); L.add(pre + "emb_layers.1.bias", {l.cout});
+    L.add(pre + "out_layers.0.weight", {l.cout}); L.add(pre + "out_layers.0.bias", {l.cout});
+    L.add(pre + "out_layers.3.weight", {l.cout, l.cout, 3, 3}); L.add(pre + "out_layers.3.bias", {l.cout});
+    if (l.cin != l.cout) { L.add(pre + "skip_connection.weight", {l.cout, l.cin, 1, 1}); L.add(pre + "skip_connection.bias", {l.cout}); }
+  } else if (l.kind == 2) {
+    L.add(pre + "norm.weight", {l.cin}); L.add(pre + "norm.bias", {l.cin});
+    L.add(pre + "qkv.weight", {3 * l.cin, l.cin, 1}); L.add(pre + "qkv.bias", {3 * l.cin});
+    L.add(pre + "proj_out.weight", {l.cin, l.cin, 1}); L.add(pre + "proj_out.bias", {l.cin});
+  } else if (l.kind == 3) { L.add(pre + "op.weight", {l.cin, l.cin, 3, 3}); L.add(pre + "op.bias", {l.cin}); }
+  else { L.add(pre + "conv.weight", {l.cin, l.cin, 3, 3}); L.add(pre + "conv.bias", {l.cin}); }
+}
+
+}  // namespace
+
+std::vector<TensorSpec> unet_oa_tensor_specs(const UnetOACfg& c) {
+  SpecList L;
+  const int emb = c.model_channels * 4;
+  L.add("time_embed.0.weight", {emb, c.model_channels}); L.add("time_embed.0.bias", {emb});
+  L.add("time_embed.2.weight", {emb, emb}); L.add("time_embed.2.bias", {emb});
+  if (c.use_z) {
+    L.add("proj.0.weight", {emb, c.z_dim}); L.add("proj.0.bias", {emb});
+    L.add("proj.2.weight", {emb, emb}); L.add("proj.2.bias", {emb});
+  }
+  OAStruct S = oa_structure(c);
+  for (size_t b = 0; b < S.inputs.size(); ++b) for (size_t l = 0; l < S.inputs[b].size(); ++l)
+    oa_layer_specs(L, "input_blocks." + std::to_string(b) + "." + std::to_string(l) + ".", S.inputs[b][l], emb);
+  for (size_t l = 0; l < S.middle.size(); ++l) oa_layer_specs(L, "middle_block." + std::to_string(l) + ".", S.middle[l], emb);
+  for (size_t b = 0; b < S.outputs.size(); ++b) for (size_t l = 0; l < S.outputs[b].size(); ++l)
+    oa_layer_specs(L, "output_blocks." + std::to_string(b) + "." + std::to_string(l) + ".", S.outputs[b][l], emb);
+  L.add("out.0.weight", {c.model_channels}); L.add("out.0.bias", {c.model_channels});
+  L.add("out.2.weight", {c.out_channels, c.model_channels, 3, 3}); L.add("out.2.bias", {c.out_channels});
+  return L.v;
+}
+
+bool build_unet_oa_plan(const UnetOACfg& cfg, int B, int with_z, const float* const* tensors, Plan* plan) {
+  try {
+    std::vector<TensorSpec> specs = unet_oa_tensor_specs(cfg);
+    Builder b(plan, B, specs, tensors);
+    if (with_z && !cfg.use_z) throw std::runtime_error("plan: z given but the model has no proj (use_z=False)");
+    OAStruct S = oa_structure(cfg);
+    const int mc = cfg.model_channels, emb = mc * 4;
+    plan->in_C = cfg.in_channels; plan->in_H = cfg.H; plan->in_W = cfg.W;
+    plan->out_C = cfg.out_channels; plan->out_H = cfg.H; plan->out_W = cfg.W;
+    plan->needs_time = 1;
+    for (int v : {mc}) if (v % 32) throw std::runtime_error("plan: UNetModel channel counts must be multiples of 32 (GroupNorm32)");
+
+    View xin = b.new_act(cfg.H, cfg.W, cfg.in_channels);
+    { Op& op = b.push(OP_NCHW_TO_PBC, "input"); op.cv.B = B; op.cv.C = cfg.in_channels; op.cv.Hn = cfg.H; op.cv.Wn = cfg.W; op.cv.out = xin; }
+
+    // ---- emb = time_embed(timestep_embedding(t)) [+ proj(z)]; every ResBlock starts its emb path with SiLU ----
+    plan->time_off = b.ws_alloc(B);
+    View e0 = b.new_act(1, 1, mc);
+    {
+      Op& op = b.push(OP_SINUS, "timestep_embedding"); op.si.B = B; op.si.dim = mc; op.si.out_off = e0.off; op.si.ld = e0.ld; op.si.cos_first = 1;
+      const int half = mc / 2;
+      std::vector<float> fr(half);
+      for (int j = 0; j < half; ++j) { const float arg = (float)(-std::log(10000.0)) * (float)j / (float)half; fr[j] = (float)std::exp((double)arg); }   // unet_openai.py:75-77
+      op.si.freq_off = b.add_params(fr);
+    }
+    auto linear = [&](const std::string& name, const View& a, int cin, int cout, int act, const View* res) {
+      Builder::ConvSpec l; l.name = name; l.a = a; l.cm = ChanMap::identity(cin); l.cin_true = cin;
+      l.w = b.T(name + ".weight", (int64_t)cout * cin); l.bias = b.T(name + ".bias", cout); l.cout = cout; l.act = act;
+      if (res) { l.has_res = true; l.r = *res; }
+      return b.emit_conv(l).out;
+    };
+    View e1 = linear("time_embed.0", e0, mc, emb, ACT_SILU, nullptr);
+    View embs;
+    if (with_z) {
+      View e2 = linear("time_embed.2", e1, emb, emb, ACT_NONE, nullptr);
+      plan->aux_C = cfg.z_dim;
+      View zin; zin.H = zin.W = 1; zin.C = pad8(cfg.z_dim); zin.ld = zin.C; zin.off = b.ws_alloc((int64_t)B * zin.ld);
+      if (zin.C != cfg.z_dim) throw std::runtime_error("plan: z_dim must be a multiple of 8");
+      plan->aux_off = zin.off;
+      View z1 = linear("proj.0", zin, cfg.z_dim, emb, ACT_SILU, nullptr);
+      embs = linear("proj.2", z1, emb, emb, ACT_SILU, &e2);          // SiLU(emb + z_proj): first op of every emb_layers
+    } else {
+      embs = linear("time_embed.2", e1, emb, emb, ACT_SILU, nullptr);
+    }
+    // all ResBlock.emb_layers.1 Linears as one GEMM
+    struct RB { std::string pre; int cout; int col; };
+    std::vector<RB> rbs;
+    auto collect = [&](const std::string& pre, const OALayer& l) { if (l.kind == 1) rbs.push_back({pre, l.cout, 0}); };
+    for (size_t bi = 0; bi < S.inputs.size(); ++bi) for (size_t l = 0; l < S.inputs[bi].size(); ++l) collect("input_blocks." + std::to_string(bi) + "." + std::to_string(l) + ".", S.inputs[bi][l]);
+    for (size_t l = 0; l < S.middle.size(); ++l) collect("middle_block." + std::to_string(l) + ".", S.middle[l]);
+    for (size_t bi = 0; bi < S.outputs.size(); ++bi) for (size_t l = 0; l < S.outputs[bi].size(); ++l) collect("output_blocks." + std::to_string(bi) + "." + std::to_string(l) + ".", S.outputs[bi][l]);
+    int cond_ld = 0;
+    for (auto& r : rbs) { r.col = cond_ld; cond_ld += pad8(r.cout); }
+    std::map<std::string, int> cond_col;
+    for (auto& r : rbs) cond_col[r.pre] = r.col;
+    View cond_all = b.new_act(1, 1, cond_ld);
+    {
+      const int Kp = round_up(emb, 32), Npad = round_up(cond_ld, 32);
+      std::vector<float> w((size_t)Npad * Kp, 0.f), bb(Npad, 0.f);
+      for (auto& r : rbs) {
+        const float* ww = b.T(r.pre + "emb_layers.1.weight", (int64_t)r.cout * emb); const float* wb = b.T(r.pre + "emb_layers.1.bias", r.cout);
+        for (int c = 0; c < r.cout; ++c) { std::memcpy(&w[(size_t)(r.col + c) * Kp], &ww[(size_t)c * emb], sizeof(float) * emb); bb[r.col + c] = wb[c]; }
+        plan->flops_dense += 2.0 * B * r.cout * emb; plan->flops_dense_gemm += 2.0 * B * r.cout * emb;
+      }
+      Op& op = b.push(OP_GEMM, "emb_layers.1 (all ResBlocks)");
+      GemmOp& g = op.g; g.B = B; g.a = embs; g.N = cond_ld; g.Npad = Npad; g.Kp = Kp; g.out = cond_all;
+      g.w_off = b.add_params(w); g.bias_off = b.add_params(bb);
+      Builder::choose_tile(B, 1, cond_ld, &g.BM, &g.BN);
+      op.flops = 2.0 * B * Npad * emb; plan->flops_exec += op.flops;
+    }
+
+    // ---- layer emitters ----
+    auto gn32 = [&](const std::string& pre, const View& x, int C, bool silu) {
+      View y = b.new_act(x.H, x.W, C);
+      Op& op = b.push(OP_GN32, pre + (silu ? "+silu" : ""));
+      op.gn.B = B; op.gn.in = x; op.gn.out = y; op.gn.groups = 32; op.gn.silu = silu ? 1 : 0;
+      op.gn.gamma_off = b.add_params(b.pack_vec(b.T(pre + "weight", C), C, nullptr, C));
+      op.gn.beta_off = b.add_params(b.pack_vec(b.T(pre + "bias", C), C, nullptr, C));
+      return y;
+    };
+    auto conv3 = [&](const std::string& pre, const View& a, int cin, int cout, int stride, int up, View* dest) {
+      Builder::ConvSpec c; c.name = pre; c.a = a; c.cm = ChanMap::identity(cin); c.cin_true = cin; c.kh = c.kw = 3; c.pad = 1; c.stride = stride; c.up = up;
+      c.w = b.T(pre + ".weight", (int64_t)cout * cin * 9); c.bias = b.T(pre + ".bias", cout); c.cout = cout;
+      c.Hout = a.H * up / stride; c.Wout = a.W * up / stride; c.dest = dest;
+      return b.emit_conv(c).out;
+    };
+    auto resblock = [&](const std::string& pre, const View& x, int cin, int cout, View* dest) {
+      View xs = gn32(pre + "in_layers.0.", x, cin, true);
+      Builder::ConvSpec c1; c1.name = pre + "in_layers.2"; c1.a = xs; c1.cm = ChanMap::identity(cin); c1.cin_true = cin; c1.kh = c1.kw = 3; c1.pad = 1;
+      c1.w = b.T(pre + "in_layers.2.weight", (int64_t)cout * cin * 9); c1.bias = b.T(pre + "in_layers.2.bias", cout); c1.cout = cout; c1.Hout = x.H; c1.Wout = x.W;
+      // + emb_out[:, :, None, None]: a 1-pixel residual read by every output pixel (up2 >= grid size maps all pixels to p2 = 0)
+      c1.has_res = true; c1.r = cond_all; c1.r.off = cond_all.off + cond_col.at(pre); c1.r.C = pad8(cout); c1.up2 = 1 << 20;
+      View h1 = b.emit_conv(c1).out;
+      b.free_act(xs);
+      View hs = gn32(pre + "out_layers.0.", h1, cout, true);
+      b.free_act(h1);
+      Builder::ConvSpec c2; c2.name = pre + "out_layers.3"; c2.a = hs; c2.cm = ChanMap::identity(cout); c2.cin_true = cout; c2.kh = c2.kw = 3; c2.pad = 1;
+      c2.w = b.T(pre + "out_layers.3.weight", (int64_t)cout * cout * 9); c2.bias = b.T(pre + "out_layers.3.bias", cout); c2.cout = cout; c2.Hout = x.H; c2.Wout = x.W;
+      if (cin != cout) { c2.has2 = true; c2.a2 = x; c2.cm2 = ChanMap::identity(cin); c2.cin2 = cin; c2.w2 = b.T(pre + "skip_connection.weight", (int64_t)cout * cin); c2.bias2 = b.T(pre + "skip_connection.bias", cout); }
+      else { c2.has_res = true; c2.r = x; }
+      c2.dest = dest;
+      View o = b.emit_conv(c2).out;
+      b.free_act(hs);
+      return o;
+    };
+    auto attnblock = [&](const std::string& pre, const View& x, int ch, View* dest) {
+      View n = gn32(pre + "norm.", x, ch, false);
+      Builder::ConvSpec q; q.name = pre + "qkv"; q.a = n; q.cm = ChanMap::identity(ch); q.cin_true = ch;
+      q.w = b.T(pre + "qkv.weight", (int64_t)3 * ch * ch); q.bias = b.T(pre + "qkv.bias", 3 * ch); q.cout = 3 * ch; q.Hout = x.H; q.Wout = x.W;
+      View qkv = b.emit_conv(q).out;
+      b.free_act(n);
+      View att = b.new_act(x.H, x.W, ch);
+      {
+        Op& op = b.push(OP_ATTN_QKV, pre + "attention");
+        op.aq.B = B; op.aq.qkv = qkv; op.aq.out = att; op.aq.heads = cfg.num_heads; op.aq.chh = ch / cfg.num_heads;
+        op.aq.scale = (float)(1.0 / std::sqrt(std::sqrt((double)(ch / cfg.num_heads))));
+        if (x.H * x.W > 64) throw std::runtime_error("plan: AttentionBlock over more than 64 positions is not built");
+      }
+      b.free_act(qkv);
+      Builder::ConvSpec o; o.name = pre + "proj_out"; o.a = att; o.cm = ChanMap::identity(ch); o.cin_true = ch;
+      o.w = b.T(pre + "proj_out.weight", (int64_t)ch * ch); o.bias = b.T(pre + "proj_out.bias", ch); o.cout = ch; o.Hout = x.H; o.Wout = x.W;
+      o.has_res = true; o.r = x; o.dest = dest;
+      View y = b.emit_conv(o).out;
+      b.free_act(att);
+      return y;
+    };
+
+    // ---- concat buffers: output block j reads cat([h, hs.pop()]); input block n_in-1-j writes its half directly ----
+    const int n_in = (int)S.inputs.size(), n_out = (int)S.outputs.size();
+    if (n_in != n_out) throw std::runtime_error("plan: UNetModel skip stack mismatch");
+    std::vector<int> in_H(n_in);      // spatial size of each input block's output
+    { int H = cfg.H; for (int bi = 0; bi < n_in; ++bi) { for (auto& l : S.inputs[bi]) if (l.kind == 3) H /= 2; in_H[bi] = H; } }
+    // channel count entering each output block from the previous stage
+    std::vector<int> prev_ch(n_out);
+    { int ch = S.middle.back().cout; for (int j = 0; j < n_out; ++j) { prev_ch[j] = ch; ch = S.outputs[j][0].cout; } }
+    std::vector<View> cat(n_out);
+    for (int j = 0; j < n_out; ++j) {
+      const int bi = n_in - 1 - j, Hs = in_H[bi], Ws = Hs * cfg.W / cfg.H;
+      View cb; cb.H = Hs; cb.W = Ws; cb.C = prev_ch[j] + S.chans[bi]; cb.ld = cb.C; cb.off = b.ws_alloc((int64_t)Hs * Ws * B * cb.ld);
+      if (prev_ch[j] % 8 || S.chans[bi] % 8) throw std::runtime_error("plan: UNetModel channels must be multiples of 8");
+      cat[j] = cb;
+    }
+    auto skip_dest = [&](int bi) { View d = cat[n_in - 1 - bi]; d.off += prev_ch[n_in - 1 - bi]; d.C = S.chans[bi]; return d; };
+    auto main_dest = [&](int j) { View d = cat[j]; d.C = prev_ch[j]; return d; };
+
+    // ---- input blocks ----
+    View h = xin;
+    for (int bi = 0; bi < n_in; ++bi) {
+      const std::string pb = "input_blocks." + std::to_string(bi) + ".";
+      for (size_t li = 0; li < S.inputs[bi].size(); ++li) {
+        const OALayer& l = S.inputs[bi][li];
+        const bool last = li + 1 == S.inputs[bi].size();
+        View d = skip_dest(bi); View* dp = last ? &d : nullptr;
+        const std::string pre = pb + std::to_string(li) + ".";
+        View y;
+        if (l.kind == 0) y = conv3(pre.substr(0, pre.size() - 1), h, l.cin, l.cout, 1, 1, dp);
+        else if (l.kind == 1) y = resblock(pre, h, l.cin, l.cout, dp);
+        else if (l.kind == 2) y = attnblock(pre, h, l.cin, dp);
+        else y = conv3(pre + "op", h, l.cin, l.cin, 2, 1, dp);
+        h = y;
+      }
+    }
+    // ---- middle ----
+    for (size_t li = 0; li < S.middle.size(); ++li) {
+      const OALayer& l = S.middle[li];
+      const std::string pre = "middle_block." + std::to_string(li) + ".";
+      View d = main_dest(0); View* dp = li + 1 == S.middle.size() ? &d : nullptr;
+      h = l.kind == 1 ? resblock(pre, h, l.cin, l.cout, dp) : attnblock(pre, h, l.cin, dp);
+    }
+    // ---- output blocks ----
+    for (int j = 0; j < n_out; ++j) {
+      const std::string pb = "output_blocks." + std::to_string(j) + ".";
+      h = cat[j];
+      for (size_t li = 0; li < S.outputs[j].size(); ++li) {
+        const OALayer& l = S.outputs[j][li];
+        const bool last = li + 1 == S.outputs[j].size();
+        View d; View* dp = nullptr;
+        if (last && j + 1 < n_out) { d = main_dest(j + 1); dp = &d; }
+        const std::string pre = pb + std::to_string(li) + ".";
+        if (l.kind == 1) h = resblock(pre, h, l.cin, l.cout, dp);
+        else if (l.kind == 2) h = attnblock(pre, h, l.cin, dp);
+        else h = conv3(pre + "conv", h, l.cin, l.cin, 1, 2, dp);
+      }
+    }
+    // ---- out: GroupNorm32 -> SiLU -> conv3x3 ----
+    View hs = gn32("out.0.", h, mc, true);
+    Builder::ConvSpec fc; fc.name = "out.2"; fc.a = hs; fc.cm = ChanMap::identity(mc); fc.cin_true = mc; fc.kh = fc.kw = 3; fc.pad = 1;
+    fc.w = b.T("out.2.weight", (int64_t)cfg.out_channels * mc * 9); fc.bias = b.T("out.2.bias", cfg.out_channels);
+    fc.cout = cfg.out_channels; fc.Hout = cfg.H; fc.Wout = cfg.W; fc.out_nchw = true; fc.Hn = cfg.H; fc.Wn = cfg.W;
+    b.emit_conv(fc);
+    finalize_gemm_tables(plan);
+    return true;
+  } catch (const std::exception& e) {
+    plan->error = e.what();
+    return false;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // decoders
 // ------------------------------------------------------------------------------------------------
 namespace {

@@ -32,6 +32,8 @@ enum OpKind : int {
   OP_NCHW_TO_PBC = 6, // API boundary: (B,C,H,W) -> [P][B][ld] with zero channel / spatial padding
   OP_BILINEAR = 7,    // bilinear upsample (align_corners=False) PBC -> PBC
   OP_GN_FINAL = 8,    // reduce GroupNorm partials to one partial (used when there are many)
+  OP_GN32 = 9,        // GroupNorm(G, C) (+ SiLU) materialised: unet_openai normalization()
+  OP_ATTN_QKV = 10,   // unet_openai QKVAttention core (softmax over T tokens, any head width)
 };
 
 // A view of an activation tensor inside the workspace arena.
@@ -116,7 +118,12 @@ struct GnResOp {
   int64_t gamma_off = 0, beta_off = 0;
 };
 
-struct SinusOp { int B = 0; int dim = 0; int64_t out_off = 0; int ld = 0; int64_t freq_off = 0; /* params [dim/2] */ };
+struct SinusOp { int B = 0; int dim = 0; int64_t out_off = 0; int ld = 0; int64_t freq_off = 0; /* params [dim/2] */ int cos_first = 0; };
+
+struct Gn32Op { int B = 0; View in, out; int groups = 32; int silu = 0; int64_t gamma_off = 0, beta_off = 0; };
+
+// qkv channels per head h: [q | k | v] at h*3*chh (unet_openai.py:333,351-352); out channels h*chh
+struct AttnQkvOp { int B = 0; View qkv, out; int heads = 1, chh = 0; float scale = 0.f; };
 
 struct CvtOp { int B = 0; int C = 0; int Hn = 0, Wn = 0; int pad_y = 0, pad_x = 0; View out; };
 
@@ -128,7 +135,7 @@ struct Op {
   int kind = 0;
   std::string name;       // reference layer this op implements (for profiles and error messages)
   double flops = 0;       // 2*MAC this op issues (padding taps skipped, channel padding included)
-  GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf;
+  GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf; Gn32Op gn; AttnQkvOp aq;
 };
 
 struct ChunkDesc { int a_off, w_off, gkc, flags; };
@@ -147,6 +154,7 @@ struct Plan {
   int out_C = 0, out_H = 0, out_W = 0;
   int needs_time = 0;
   int64_t time_off = -1;         // workspace [B] : the plan's time input is copied here
+  int64_t aux_off = -1; int aux_C = 0;   // workspace [B][aux_C]: auxiliary conditioning input (UNetModel z), copied before a run
   double flops_dense = 0;        // 2*MAC, dense convention (zero-padding taps counted)
   double flops_exec = 0;         // 2*MAC actually issued (padding taps skipped, channel padding included)
   double flops_dense_gemm = 0;   // the part of flops_dense computed by seg_gemm launches
@@ -179,6 +187,17 @@ struct ResDecCfg {
 };
 std::vector<TensorSpec> resdec_tensor_specs(const ResDecCfg& cfg);   // decoder-side entries only
 bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const* tensors, Plan* plan);
+
+struct UnetOACfg {
+  int in_channels = 3, model_channels = 128, out_channels = 3, num_res_blocks = 2;
+  int n_mult = 4; int channel_mult[8] = {1, 2, 4, 8, 0, 0, 0, 0};
+  int n_attn = 0; int attn_res[8] = {0};
+  int num_heads = 1, z_dim = 0, use_z = 0;
+  int H = 16, W = 16;
+};
+std::vector<TensorSpec> unet_oa_tensor_specs(const UnetOACfg& cfg);
+// reference unet_openai.UNetModel.forward (unet_openai.py:538-575); with_z selects the `z is not None` branch
+bool build_unet_oa_plan(const UnetOACfg& cfg, int B, int with_z, const float* const* tensors, Plan* plan);
 
 struct AttrDecCfg { int size_z = 256, att_size = 18; };
 std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& cfg);

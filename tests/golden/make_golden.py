@@ -215,3 +215,29 @@ if __name__ == "__main__":
         trajectory_cases()
     if "dec" in which:
         decoder_cases()
+
+
+def unet_openai_cases():
+    """unet_openai.UNetModel: two toy widths (one with attention inside the blocks) and the full config-5 net."""
+    from unet_openai import UNetModel
+    from score_based_multimodal_autoencoder_amd import arch
+    out = {}
+    for name, kw, B, hw in [
+            ("oa_tiny", dict(in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(), channel_mult=(1, 2), z_dim=16, use_z=True), 2, 8),
+            ("oa_attn", dict(in_channels=2, model_channels=32, out_channels=2, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2), z_dim=16, use_z=True), 2, 4),
+            ("oa_C3c", dict(in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(), channel_mult=(1, 2, 4, 8), z_dim=512, use_z=True), 1, 16)]:
+        m = UNetModel(kw["in_channels"], kw["model_channels"], kw["out_channels"], kw["num_res_blocks"], kw["attention_resolutions"], 0.1,
+                      kw["channel_mult"], num_heads=1, use_z=True, z_dim=kw["z_dim"]).eval()
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(s) for k, s in arch.unet_openai_entries(**kw)}
+        synth.fill_module_(m)          # also re-randomises the zero_module convolutions
+        k = len(out) // 5
+        x = synth.noise(77, 5 * k, (B, kw["in_channels"], hw, hw)); t = np.array([0.7, 1e-3], np.float32)[:B]
+        z = synth.noise(78, 5 * k, (B, kw["z_dim"]))
+        out.update({name + "_x": x, name + "_t": t, name + "_z": z,
+                    name + "_y": m(torch.from_numpy(x), torch.from_numpy(t), z=torch.from_numpy(z)).numpy(),
+                    name + "_y_noz": m(torch.from_numpy(x), torch.from_numpy(t)).numpy()})
+    save("unet_openai.npz", **out)
+
+
+if __name__ == "__main__" and "openai" in sys.argv[1:]:
+    unet_openai_cases()

@@ -40,6 +40,7 @@ def lib():
         L.sbmref_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.sbmref_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         L.sbmref_free.argtypes = [ctypes.c_void_p]
+        L.sbmref_run_aux.argtypes = [ctypes.c_void_p] * 5
         L.sbmref_run_range.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.sbmref_op_name.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int]
         L.sbmref_workspace.restype = ctypes.POINTER(ctypes.c_float)
@@ -63,6 +64,12 @@ def resdec_cfg_ints(variant, enc, dec, size_in, size_z, img_ch):
     for d in dec:
         v += list(d)
     return v
+
+
+def unet_oa_cfg_ints(in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions, channel_mult, H, W,
+                     num_heads=1, z_dim=0, use_z=False):
+    return [in_channels, model_channels, out_channels, num_res_blocks, num_heads, z_dim or 0, int(bool(use_z)), H, W,
+            len(channel_mult)] + list(channel_mult) + [len(attention_resolutions)] + list(attention_resolutions)
 
 
 def specs(kind, cfg):
@@ -101,6 +108,16 @@ class RefPlan:
             t = np.ascontiguousarray(t, dtype=np.float32)
             tp = t.ctypes.data
         lib().sbmref_run(self.h, x.ctypes.data, tp, out.ctypes.data)
+        return out
+
+    def run_aux(self, x, t, aux, out_shape):
+        x = np.ascontiguousarray(x, dtype=np.float32); t = np.ascontiguousarray(t, dtype=np.float32)
+        out = np.full(out_shape, np.nan, dtype=np.float32)
+        ap = None
+        if aux is not None:
+            aux = np.ascontiguousarray(aux, dtype=np.float32)
+            ap = aux.ctypes.data
+        lib().sbmref_run_aux(self.h, x.ctypes.data, t.ctypes.data, ap, out.ctypes.data)
         return out
 
     def run_range(self, x, t, out, first, last):

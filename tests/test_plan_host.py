@@ -103,3 +103,26 @@ def test_attr_decoder_plan(golden, name):
     z, want = g[f"{name}_z"], g[f"{name}_y"]
     plan = planref.RefPlan(2, [256, 18], z.shape[0], sd, z_ld=256)
     assert_close(plan.run(z, None, want.shape), want, 1e-5, 1e-5 * np.abs(want).max(), name)
+
+
+OA_CASES = {
+    "oa_tiny": dict(in_channels=3, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(), channel_mult=(1, 2), z_dim=16, use_z=True),
+    "oa_attn": dict(in_channels=2, model_channels=32, out_channels=2, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2), z_dim=16, use_z=True),
+}
+
+
+@pytest.mark.parametrize("name", ["oa_tiny", "oa_attn"])
+@pytest.mark.parametrize("with_z", [True, False])
+def test_unet_openai_plan_matches_reference(golden, name, with_z):
+    """unet_openai.UNetModel (config-5 score net): plan + interpreter vs the reference's outputs, with and without z."""
+    g = golden("unet_openai.npz")
+    kw = OA_CASES[name]
+    x, t, z = g[f"{name}_x"], g[f"{name}_t"], g[f"{name}_z"]
+    want = g[f"{name}_y"] if with_z else g[f"{name}_y_noz"]
+    sd = synth.fill_state_dict(arch.unet_openai_state_shapes(**kw))
+    cfg = planref.unet_oa_cfg_ints(kw["in_channels"], kw["model_channels"], kw["out_channels"], kw["num_res_blocks"],
+                                   kw["attention_resolutions"], kw["channel_mult"], x.shape[2], x.shape[3], 1, kw["z_dim"], True)
+    assert planref.specs(3, cfg) == [(k, int(np.prod(s))) for k, s in arch.unet_openai_entries(**kw)]
+    plan = planref.RefPlan(3, cfg, x.shape[0], sd, z_ld=int(with_z))
+    y = plan.run_aux(x, t, z if with_z else None, want.shape)
+    assert_close(y, want, 1e-5, 1e-5 * np.abs(want).max(), name)
