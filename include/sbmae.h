@@ -30,7 +30,8 @@ enum sbm_kind {
   SBM_UNET = 0,    /* unet_model.Unet (ConvNeXt score net)                 unet_model.py:189-323 */
   SBM_RESDEC = 1,  /* h_vae_model_copy.ResVAE/ResAE/ResVAEN/ResAEN.decoder  h_vae_model_copy.py:123-126,166-169,489-492,576-579 */
   SBM_ATTRDEC = 2, /* h_vae_model.CelebAAttrNewBN[AE].decoder               h_vae_model.py:768-769,888-890 */
-  SBM_UNET_OA = 3  /* unet_openai.UNetModel (conditional CelebA score net)   unet_openai.py:361-575 */
+  SBM_UNET_OA = 3, /* unet_openai.UNetModel (conditional CelebA score net)   unet_openai.py:361-575 */
+  SBM_MLP = 4      /* lat_sm2_model.LSMPoly64_sm (MLP score, DSM Langevin)   lat_sm2_model.py:348-371; cfg [n_mod, size_z] */
 };
 
 /* Integer configuration vectors (`cfg`):
@@ -109,6 +110,19 @@ int sbm_em_step(const sbm_sde_cfg* sde, const float* x, const float* score, cons
 int sbm_langevin_step(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t,
                       const float* alphas, float* x_out, float* mean_out, float* norms_scratch, int B, int CHW,
                       uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream);
+
+/* Fixed-step Langevin update of the alternative samplers, on the joint state (B, n_mod, per_mod):
+ *   x_out[:, m] = x[:, m] + a * (score[:, m] / score_div) + b * noise[:, m]  for modalities m with bit m of mod_mask set, x[:, m] otherwise.
+ *   annealed Langevin (fid_upd10.gen_ae :97, eval_lat_celeba_hq_all.evaluate :258-275): a = alpha, score_div = sigma_i, b = c*sqrt(2*alpha)
+ *   MLP-score Langevin (fid_upd10.calc_poly_uncond :331): a = lr1, score_div = 1, b = lr2.   noise == NULL: in-kernel Philox. */
+int sbm_langevin_fixed_step(const float* x, const float* score, const float* noise, float* x_out, float a, float b, float score_div,
+                            unsigned mod_mask, int B, int n_mod, int per_mod, uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream);
+
+/* Conditional loop: re-noise the OBSERVED modalities at time t, x_out[:, m] = mean(t)*z_obs[:, m] + std(t)*z_obs[:, m]
+ * for bit m of obs_mask set (the reference multiplies std by z itself, train_poly_unet_cont.py:363-364), x[:, m] otherwise;
+ * mean/std = SDE.marginal_prob (sde_helper2.py:358-362, 409-413, 452-455). */
+int sbm_renoise_observed(const sbm_sde_cfg* sde, const float* x, const float* z_obs, const float* t, float* x_out, unsigned obs_mask,
+                         int B, int n_mod, int per_mod, void* stream);
 
 /* out[b, :] = scale * N(0,1) from the same Philox stream (prior draw: SDE.prior_sampling, sde_helper2.py:364,415,457) */
 int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_t sample_offset, int step, int draw,

@@ -14,13 +14,13 @@ LIB_PATH = os.path.join(CSRC, "libsbmae_hip.so")
 SOURCES = ["plan.cpp", "kernels.hip", "sampler.hip", "api.hip"]
 HEADERS = ["plan.h", "device.h", os.path.join("..", "..", "include", "sbmae.h")]
 
-SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA = 0, 1, 2, 3
+SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA, SBM_MLP = 0, 1, 2, 3, 4
 OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "nchw_to_pbc", "bilinear", "gn_final", "gn32",
                  "attn_qkv"]
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
            "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_em_step", "sbm_langevin_step",
-           "sbm_fill_normal", "sbm_sampler_run", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
+           "sbm_fill_normal", "sbm_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps"]
 
 
@@ -82,6 +82,9 @@ def lib():
         L.sbm_model_profile.argtypes = [vp, vp, vp, vp, i, ctypes.POINTER(dbl), ip, i]
         L.sbm_em_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, vp]
         L.sbm_langevin_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
+        L.sbm_langevin_fixed_step.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint, i, i, i, u64, u64, i, i,
+                                              vp]
+        L.sbm_renoise_observed.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, ctypes.c_uint, i, i, i, vp]
         L.sbm_fill_normal.argtypes = [vp, ctypes.c_long, i, u64, u64, i, i, ctypes.c_float, vp]
         L.sbm_sampler_run.argtypes = [vp, ctypes.POINTER(SdeCfg), ctypes.POINTER(SamplerCfg), vp, vp, vp, vp, vp, i, i,
                                       ctypes.POINTER(ctypes.c_float), vp]

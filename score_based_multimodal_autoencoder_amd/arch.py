@@ -288,3 +288,20 @@ def unet_openai_entries(in_channels, model_channels, out_channels, num_res_block
 
 def unet_openai_state_shapes(**kw):
     return dict(unet_openai_entries(**kw))
+
+
+_MLP_MUL = (1, 2, 6, 6, 4, 2, 1, 1)
+
+
+def mlp_entries(n_mod=5, size_z=128):
+    """state_dict of lat_sm2_model.LSMPoly64_sm (lat_sm2_model.py:348-371): nn.Sequential 'layers', Linear at even slots."""
+    d = n_mod * size_z
+    out = []
+    for i in range(7):
+        out.append((f"layers.{2 * i}.weight", (d * _MLP_MUL[i + 1], d * _MLP_MUL[i])))
+        out.append((f"layers.{2 * i}.bias", (d * _MLP_MUL[i + 1],)))
+    return out
+
+
+def mlp_state_shapes(n_mod=5, size_z=128):
+    return dict(mlp_entries(n_mod, size_z))

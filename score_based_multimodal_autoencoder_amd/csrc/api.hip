@@ -58,6 +58,7 @@ static UnetOACfg unet_oa_cfg_from_ints(const int* c) {
 }
 static std::vector<TensorSpec> specs_of(int kind, const int* cfg) {
   if (kind == SBM_UNET_OA) return unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg));
+  if (kind == SBM_MLP) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; return mlp_tensor_specs(c); }
   if (kind == SBM_UNET) return unet_tensor_specs(unet_cfg_from_ints(cfg));
   if (kind == SBM_RESDEC) return resdec_tensor_specs(resdec_cfg_from_ints(cfg));
   if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; return attrdec_tensor_specs(a); }
@@ -119,6 +120,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   else if (kind == SBM_RESDEC) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), batch, in_pitch, host_tensors, &m->plan);
   else if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, batch, in_pitch, host_tensors, &m->plan); }
   else if (kind == SBM_UNET_OA) ok = build_unet_oa_plan(unet_oa_cfg_from_ints(cfg), batch, in_pitch, host_tensors, &m->plan);
+  else if (kind == SBM_MLP) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; ok = build_mlp_plan(c, batch, host_tensors, &m->plan); }
   else m->plan.error = "unknown model kind";
   if (!ok) { std::string e = m->plan.error; delete m; return fail("sbm_model_create: " + e); }
   const size_t pbytes = m->plan.params.size() * sizeof(float), wbytes = (size_t)m->plan.ws_floats * sizeof(float);
@@ -319,6 +321,27 @@ int sbm_langevin_step(const sbm_sde_cfg* sde, const float* x, const float* score
   StepArgs a = step_args(sde, x, score, noise, t, x_out, mean_out, B, CHW, seed, sample_offset, step, draw);
   a.alphas = alphas; a.norms = norms_scratch;
   launch_langevin_step(a, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sbm_langevin_fixed_step(const float* x, const float* score, const float* noise, float* x_out, float a, float b, float score_div, unsigned mod_mask, int B,
+                            int n_mod, int per_mod, uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream) {
+  if (!x || !score || !x_out || B <= 0 || n_mod <= 0 || n_mod > 32 || per_mod <= 0 || per_mod % 4 || !(score_div != 0.f)) return fail("sbm_langevin_fixed_step: bad arguments");
+  StepArgs s{};
+  s.x = x; s.score = score; s.noise = noise; s.x_out = x_out; s.B = B; s.CHW = n_mod * per_mod; s.seed = seed; s.sample_offset = sample_offset;
+  s.step_base = step; s.draw = draw;
+  launch_axpy_noise(s, a, b, score_div, mod_mask, per_mod, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sbm_renoise_observed(const sbm_sde_cfg* sde, const float* x, const float* z_obs, const float* t, float* x_out, unsigned obs_mask, int B, int n_mod,
+                         int per_mod, void* stream) {
+  if (!sde || !x || !z_obs || !t || !x_out || B <= 0 || n_mod <= 0 || n_mod > 32 || per_mod <= 0 || per_mod % 4) return fail("sbm_renoise_observed: bad arguments");
+  StepArgs s{};
+  s.x = x; s.t = t; s.x_out = x_out; s.B = B; s.CHW = n_mod * per_mod; s.sde = make_sde(*sde);
+  launch_renoise(s, z_obs, obs_mask, per_mod, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -23,6 +23,7 @@ static inline float act_apply(int act, float v) {
     case ACT_RELU: return v > 0.f ? v : 0.f;
     case ACT_SIGMOID: return (float)(1.0 / (1.0 + std::exp(-(double)v)));
     case ACT_SILU: return (float)((double)v / (1.0 + std::exp(-(double)v)));
+    case ACT_SOFTPLUS: return v > 20.f ? v : (float)std::log1p(std::exp((double)v));
     default: return v;
   }
 }
@@ -312,6 +313,7 @@ void* sbmref_build(int kind, const int* cfg, int B, int z_ld, const float* const
   else if (kind == 1) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);
   else if (kind == 2) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, B, z_ld, tensors, &h->plan); }
   else if (kind == 3) ok = build_unet_oa_plan(unet_oa_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);
+  else if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; ok = build_mlp_plan(c, B, tensors, &h->plan); }
   if (!ok) { g_err = h->plan.error.empty() ? "unknown plan kind" : h->plan.error; delete h; return nullptr; }
   h->ws.assign((size_t)h->plan.ws_floats, std::nanf(""));      // poison: every read must be preceded by a write
   return h;
@@ -321,6 +323,7 @@ int sbmref_num_specs(int kind, const int* cfg) {
   if (kind == 0) return (int)unet_tensor_specs(unet_cfg_from_ints(cfg)).size();
   if (kind == 1) return (int)resdec_tensor_specs(resdec_cfg_from_ints(cfg)).size();
   if (kind == 3) return (int)unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg)).size();
+  if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; return (int)mlp_tensor_specs(c).size(); }
   AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1];
   return (int)attrdec_tensor_specs(a).size();
 }
@@ -330,6 +333,7 @@ long sbmref_spec(int kind, const int* cfg, int i, char* name, int cap) {
   if (kind == 0) s = unet_tensor_specs(unet_cfg_from_ints(cfg));
   else if (kind == 1) s = resdec_tensor_specs(resdec_cfg_from_ints(cfg));
   else if (kind == 3) s = unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg));
+  else if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; s = mlp_tensor_specs(c); }
   else { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; s = attrdec_tensor_specs(a); }
   if (i < 0 || i >= (int)s.size()) return -1;
   std::strncpy(name, s[i].name.c_str(), cap - 1); name[cap - 1] = 0;

@@ -27,6 +27,7 @@ DEVINL float act_apply(int act, float v) {
     case ACT_RELU: return fmaxf(v, 0.f);
     case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     case ACT_SILU: return v / (1.0f + expf(-v));
+    case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));      // nn.Softplus(beta=1, threshold=20)
     default: return v;
   }
 }

@@ -1098,6 +1098,45 @@ bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const
   }
 }
 
+static const int kMlpMul[8] = {1, 2, 6, 6, 4, 2, 1, 1};
+
+std::vector<TensorSpec> mlp_tensor_specs(const MlpCfg& c) {
+  SpecList L;
+  const int d = c.n_mod * c.size_z;
+  for (int i = 0; i < 7; ++i) {
+    std::string l = "layers." + std::to_string(2 * i) + ".";
+    L.add(l + "weight", {d * kMlpMul[i + 1], d * kMlpMul[i]}); L.add(l + "bias", {d * kMlpMul[i + 1]});
+  }
+  return L.v;
+}
+
+bool build_mlp_plan(const MlpCfg& cfg, int B, const float* const* tensors, Plan* plan) {
+  try {
+    std::vector<TensorSpec> specs = mlp_tensor_specs(cfg);
+    Builder b(plan, B, specs, tensors);
+    const int d = cfg.n_mod * cfg.size_z;
+    if (d % 32) throw std::runtime_error("plan: n_mod*size_z must be a multiple of 32");
+    plan->in_C = d; plan->in_ld = d; plan->in_H = plan->in_W = 1; plan->out_C = d; plan->out_H = plan->out_W = 1;
+    View h;
+    for (int i = 0; i < 7; ++i) {
+      const int cin = d * kMlpMul[i], cout = d * kMlpMul[i + 1];
+      std::string l = "layers." + std::to_string(2 * i);
+      Builder::ConvSpec c; c.name = l + (i < 6 ? "+softplus" : ""); c.cm = ChanMap::identity(cin); c.cin_true = cin;
+      c.w = b.T(l + ".weight", (int64_t)cout * cin); c.bias = b.T(l + ".bias", cout); c.cout = cout; c.act = i < 6 ? ACT_SOFTPLUS : ACT_NONE;
+      if (i == 0) { c.a.C = d; c.a.ld = d; c.a.H = c.a.W = 1; c.a.off = 0; } else c.a = h;
+      if (i == 6) { c.out_nchw = true; c.Hn = c.Wn = 1; }
+      Builder::ConvResult r = b.emit_conv(c);
+      if (i == 0) plan->ops.back().g.a_ext = 1; else b.free_act(h);
+      h = r.out;
+    }
+    finalize_gemm_tables(plan);
+    return true;
+  } catch (const std::exception& e) {
+    plan->error = e.what();
+    return false;
+  }
+}
+
 bool build_attrdec_plan(const AttrDecCfg& cfg, int B, int z_ld, const float* const* tensors, Plan* plan) {
   try {
     std::vector<TensorSpec> specs = attrdec_tensor_specs(cfg);

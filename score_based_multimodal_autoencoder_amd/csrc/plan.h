@@ -20,7 +20,7 @@
 
 namespace sbm {
 
-enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU02 = 2, ACT_RELU = 3, ACT_SIGMOID = 4, ACT_SILU = 5 };
+enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU02 = 2, ACT_RELU = 3, ACT_SIGMOID = 4, ACT_SILU = 5, ACT_SOFTPLUS = 6 };
 
 enum OpKind : int {
   OP_GEMM = 0,        // segmented implicit-GEMM convolution / linear (MFMA fp32)
@@ -198,6 +198,11 @@ struct UnetOACfg {
 std::vector<TensorSpec> unet_oa_tensor_specs(const UnetOACfg& cfg);
 // reference unet_openai.UNetModel.forward (unet_openai.py:538-575); with_z selects the `z is not None` branch
 bool build_unet_oa_plan(const UnetOACfg& cfg, int B, int with_z, const float* const* tensors, Plan* plan);
+
+// lat_sm2_model.LSMPoly64_sm: 7 Linear layers with Softplus between (lat_sm2_model.py:348-371)
+struct MlpCfg { int n_mod = 5, size_z = 64; };
+std::vector<TensorSpec> mlp_tensor_specs(const MlpCfg& cfg);
+bool build_mlp_plan(const MlpCfg& cfg, int B, const float* const* tensors, Plan* plan);
 
 struct AttrDecCfg { int size_z = 256, att_size = 18; };
 std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& cfg);

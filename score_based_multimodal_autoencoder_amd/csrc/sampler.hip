@@ -138,6 +138,58 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(const StepArgs a) 
   *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
 }
 
+// Fixed-step Langevin update of the alternative samplers: x_out = x + mask_c * (a * score + b * noise) per modality
+// channel c (annealed Langevin fid_upd10.py:93-97, score/sigma first, a = alpha, b = c*sqrt(2 alpha); MLP-score Langevin
+// fid_upd10.py:331, a = lr1, b = lr2).  Observed modalities (mask bit clear) pass through unchanged.
+__global__ __launch_bounds__(256) void axpy_noise_kernel(const StepArgs a, float ca, float cb, float sdiv, unsigned mod_mask, int per_mod) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q4 = a.CHW >> 2;
+  if (idx >= (long long)a.B * q4) return;
+  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
+  const float4 x = *reinterpret_cast<const float4*>(a.x + (long long)b * a.CHW + e);
+  float4 o = x;
+  if ((mod_mask >> (e / per_mod)) & 1u) {
+    float4 s = *reinterpret_cast<const float4*>(a.score + (long long)b * a.CHW + e);
+    s.x = s.x / sdiv; s.y = s.y / sdiv; s.z = s.z / sdiv; s.w = s.w / sdiv;             // score / sigma_i (fid_upd10.py:93); exact for sdiv = 1
+    const float4 z = load_noise4(a, b, e, (unsigned)a.step_base);
+    o.x = (x.x + ca * s.x) + cb * z.x; o.y = (x.y + ca * s.y) + cb * z.y; o.z = (x.z + ca * s.z) + cb * z.z; o.w = (x.w + ca * s.w) + cb * z.w;
+  }
+  *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
+}
+void launch_axpy_noise(const StepArgs& a, float ca, float cb, float sdiv, unsigned mod_mask, int per_mod, hipStream_t st) {
+  const long long n = (long long)a.B * (a.CHW >> 2);
+  hipLaunchKernelGGL(axpy_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, ca, cb, sdiv, mod_mask, per_mod);
+}
+
+// Re-noising of the observed modalities in the conditional loop (train_poly_unet_cont.py:356-364,
+// train_lat_celebhq_unet_cont2.py:293-301): x_out[:, c] = mean_coef(t) * z_obs[:, c] + std(t) * z_obs[:, c] for observed c
+// (the reference multiplies std by z itself, not by fresh noise -- reproduced knowingly), x[:, c] otherwise.
+__global__ __launch_bounds__(256) void renoise_kernel(const StepArgs a, const float* z_obs, unsigned obs_mask, int per_mod) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q4 = a.CHW >> 2;
+  if (idx >= (long long)a.B * q4) return;
+  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
+  float4 o = *reinterpret_cast<const float4*>(a.x + (long long)b * a.CHW + e);
+  if ((obs_mask >> (e / per_mod)) & 1u) {
+    const float t = a.t ? a.t[b] : a.timesteps[a.step_counter ? *a.step_counter : a.step_base];
+    float mc = 1.f, sd;
+    if (a.sde.kind == 2) sd = a.sde.b0 * powf(a.sde.ve_ratio, t);
+    else {
+      const float lmc = (-0.25f * (t * t)) * a.sde.b1_minus_b0 - (0.5f * t) * a.sde.b0;     // sde_helper2.py:359
+      mc = expf(lmc);
+      const float e2 = expf(2.0f * lmc);
+      sd = a.sde.kind == 0 ? sqrtf(1.0f - e2) : 1.0f - e2;
+    }
+    const float4 z = *reinterpret_cast<const float4*>(z_obs + (long long)b * a.CHW + e);
+    o.x = mc * z.x + sd * z.x; o.y = mc * z.y + sd * z.y; o.z = mc * z.z + sd * z.z; o.w = mc * z.w + sd * z.w;
+  }
+  *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
+}
+void launch_renoise(const StepArgs& a, const float* z_obs, unsigned obs_mask, int per_mod, hipStream_t st) {
+  const long long n = (long long)a.B * (a.CHW >> 2);
+  hipLaunchKernelGGL(renoise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, z_obs, obs_mask, per_mod);
+}
+
 __global__ void fill_time_kernel(float* t_out, const float* timesteps, const int* step_counter, int B) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B) t_out[i] = timesteps[*step_counter];

@@ -292,3 +292,52 @@ def uncond_sampler(sample_shape, model, device, sde, eps=1e-3, probability_flow=
                 if pc:
                     x, x_mean = corr(x)
         return x_mean
+
+
+def renoise_observed(x, z_obs, t, sde, given, out=None):
+    """x with the observed modality channels replaced by mean(t)*z_obs + std(t)*z_obs (train_poly_unet_cont.py:356-364:
+    the reference scales the clean latent by std instead of drawing noise -- reproduced as is)."""
+    x = as_f32_cuda(x, "x")
+    z_obs = as_f32_cuda(z_obs, "z_obs")
+    t = as_f32_cuda(t, "t")
+    B, n_mod = x.shape[0], x.shape[1]
+    mask = 0
+    for m in given:
+        mask |= 1 << int(m)
+    out = torch.empty_like(x) if out is None else out
+    cfg = sde._cfg()
+    _lib.check(_lib.lib().sbm_renoise_observed(ctypes.byref(cfg), x.data_ptr(), z_obs.data_ptr(), t.data_ptr(), out.data_ptr(), mask, B, n_mod,
+                                               x[0, 0].numel(), _lib.stream_ptr()))
+    return out
+
+
+def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target_snr=0.16, noise_obs=False, *, x0=None, noise=None):
+    """Conditional generation loop of the training scripts' evaluate() (train_poly_unet_cont.py:340-381,
+    train_lat_celebhq_unet_cont2.py:277-318): channels in `given` hold the observed latents z_obs (re-noised to level t at
+    every step when noise_obs), the others start from N(0,1) (or x0) and follow the reverse SDE, predictor then corrector.
+    Returns the joint state (B, n_mod, H, W): unobserved channels = final x_mean, observed = clean z_obs."""
+    z_obs = as_f32_cuda(z_obs, "z_obs")
+    device = z_obs.device
+    B, n_mod = z_obs.shape[0], z_obs.shape[1]
+    given = sorted(int(m) for m in given)
+    keep = torch.zeros(n_mod, dtype=torch.bool, device=device)
+    keep[given] = True
+    keep = keep.view(1, n_mod, 1, 1)
+    with torch.no_grad():
+        x = (torch.randn_like(z_obs) if x0 is None else as_f32_cuda(x0, "x0")).clone()
+        x = torch.where(keep, z_obs, x)
+        timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
+        x_mean = x
+        k = 0
+        for i in range(sde.N):
+            vec_t = torch.ones(B, device=device) * timesteps[i]
+            x_in = renoise_observed(x, z_obs, vec_t, sde, given) if noise_obs else torch.where(keep, z_obs, x)
+            nz = None if noise is None else noise[k]
+            k += 1
+            x_upd, x_mean = em_predictor(x_in, vec_t, model, sde, noise=nz)
+            if pc:
+                nzs = None if noise is None else [noise[k + j] for j in range(n_steps)]
+                k += n_steps
+                x_upd, x_mean = corrector(x_upd, vec_t, model, sde, n_steps, target_snr, noise=nzs)
+            x = x_upd
+        return torch.where(keep, z_obs, x_mean)

@@ -241,3 +241,160 @@ def unet_openai_cases():
 
 if __name__ == "__main__" and "openai" in sys.argv[1:]:
     unet_openai_cases()
+
+
+# ---------------------------------------------------------------------------------------------
+# Alternative samplers and the conditional loop (f1), from the reference's OWN script functions:
+# fid_upd10.gen_ae / calc_poly_uncond and train_poly_unet_cont.evaluate are called unmodified, with deterministic noise
+# injected by patching torch.normal / torch.randn / torch.randn_like, fake one-batch loaders, and the image sinks
+# (save_batch_image / plt.imshow) replaced by recorders.
+class _Inert(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith("__"):
+            raise AttributeError(k)
+        m = _Inert(self.__name__ + "." + k)
+        setattr(self, k, m)
+        return m
+
+    def __call__(self, *a, **k):
+        return None
+
+
+class _Noise:
+    """Deterministic stand-in for torch's normal draws; logs every draw in order."""
+
+    def __init__(self, seed):
+        self.seed, self.log = seed, []
+
+    def _draw(self, kind, shape):
+        a = synth.noise(self.seed, len(self.log), tuple(shape))
+        self.log.append((kind, a))
+        return torch.from_numpy(a)
+
+    def __enter__(self):
+        self.orig = (torch.normal, torch.randn, torch.randn_like)
+        torch.normal = lambda mean=0, std=1, size=None, **kw: self._draw("normal", size)
+        torch.randn = lambda *shape, **kw: self._draw("randn", shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape)
+        torch.randn_like = lambda x, **kw: self._draw("randn_like", x.shape)
+        return self
+
+    def __exit__(self, *a):
+        torch.normal, torch.randn, torch.randn_like = self.orig
+
+
+class _Spy(torch.nn.Module):
+    """Wraps the score net and records the states it is called with."""
+
+    def __init__(self, m, keep):
+        super().__init__()
+        self.m, self.keep, self.calls, self.seen = m, set(keep), 0, {}
+
+    def forward(self, *a):
+        if self.calls in self.keep:
+            self.seen[self.calls] = a[0].detach().numpy().copy()
+        self.calls += 1
+        return self.m(*a)
+
+
+class _Tamed(torch.nn.Module):
+    """score(z, i) = 0.02 * unet(z, i) - 0.2 * z: the closed-form filler weights do not make a contracting score on their own,
+    and gen_ae's first levels step by alpha/sigma up to 5; the linear term keeps the 4000-step chain finite."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, z, i):
+        return 0.02 * self.m(z, i) - 0.2 * z
+
+
+def alt_sampler_cases():
+    for n in ("torchvision.transforms", "torchvision.utils", "torchvision.datasets", "matplotlib", "matplotlib.pyplot", "pytorch_fid",
+              "pytorch_fid.fid_score", "PIL", "PIL.Image"):
+        sys.modules.setdefault(n, _Inert(n))
+    for n in ("jax", "jax.numpy", "torchvision", "torchvision.models"):
+        sys.modules[n] = _Inert(n)
+    import fid_upd10 as FU  # noqa: E402  (reference script module; importing runs no work)
+    import lat_sm2_model as LM  # noqa: E402  (reference)
+    out = {}
+    # -- a15: MLP score forward -----------------------------------------------------------------
+    for tag, n_mod, size_z, B in (("mlp_small", 2, 16, 3), ("mlp_poly5", 5, 64, 4)):
+        m = synth.fill_module_(LM.LSMPoly64_sm(n_mod=n_mod, size_z=size_z).eval())
+        x = inp(f"alt.{tag}.x", (B, n_mod * size_z))
+        out[f"{tag}_x"], out[f"{tag}_y"] = x, m(torch.from_numpy(x)).numpy()
+    # -- a15: fid_upd10.calc_poly_uncond, 2 modalities x size_z 64, n_comp 6 ----------------------
+    vae = {k: synth.fill_module_(ResVAE(POLY_ENC, POLY_DEC, 32, 64, 3).eval()) for k in "01"}
+    sm = synth.fill_module_(LM.LSMPoly64_sm(n_mod=2, size_z=64).eval())
+    imgs = {"m" + k: torch.zeros(2, 3, 32, 32) for k in "01"}
+    for sched in (False, True):
+        sink = {}
+        FU.save_batch_image = lambda t, path, _s=sink: _s.__setitem__(path.split("/")[-1], t.numpy().copy())
+        paths = {f"unc_p2_{k}": "x/" for k in "01"}
+        with _Noise(0xA15 + int(sched)) as nz:
+            FU.calc_poly_uncond([(imgs, torch.zeros(2, dtype=torch.long))], paths, vae, sm, lambda x: torch.zeros(x.shape[0], 10), 0.03, 0.001, 6, 64,
+                                "cpu", False, schedule=sched)
+        tag = f"polyunc_s{int(sched)}"
+        out[f"{tag}_noise"] = np.stack([a for _, a in nz.log])                  # (2 + 2*n_draw_steps, B, 64): z0 per mod, then per step per mod
+        for k in "01":
+            out[f"{tag}_out{k}"] = sink[f"{k}_out_0_"]
+        print(tag, "draws", len(nz.log))
+    # -- a16: fid_upd10.gen_ae (annealed Langevin, Unet score on the sigma index) -----------------
+    for tag, mods, pred, keep in (("genae_cond", "01", "1", (0, 1, 19, 20, 21, 99, 3999)), ("genae_all2", "01", "01", (0, 1, 20, 99, 3999)),
+                                  ("genae_all10", "0123456789", "0123456789", (0, 1, 2, 3, 99, 399))):
+        n = len(mods)
+        pae = {k: synth.fill_module_(ResAE(POLY_ENC, POLY_DEC, 32, 64, 3).eval()) for k in mods}
+        score = _Spy(_Tamed(synth.fill_module_(Unet(dim=8, channels=n, dim_mults=(1, 2, 2, 2)).eval())), keep)
+        p = {k: torch.from_numpy(inp(f"alt.{tag}.p{k}", (2, 3, 32, 32), 0.25) + 0.5) for k in mods}
+        with _Noise(0xA16 + n + len(pred)) as nz:
+            y = FU.gen_ae(score, pae, pred, mods, p, 2, "cpu", 64)
+        out[f"{tag}_y"] = y.numpy()
+        out[f"{tag}_p"] = np.stack([p[k].numpy() for k in mods])
+        out[f"{tag}_seed"] = np.asarray([0xA16 + n + len(pred), len(nz.log)])
+        for k, v in score.seen.items():
+            out[f"{tag}_zin{k}"] = v
+        print(tag, "score calls", score.calls, "draws", len(nz.log), "|y| max", float(y.abs().max()))
+    save("alt_samplers.npz", **out)
+
+
+def conditional_cases():
+    """train_poly_unet_cont.evaluate: the 'pc'-order functional sampler and the conditional loop (re-noised observations)."""
+    for n in ("torchvision.transforms", "torchvision.utils", "torchvision.datasets", "matplotlib", "matplotlib.pyplot", "pytorch_fid",
+              "pytorch_fid.fid_score", "PIL", "PIL.Image"):
+        sys.modules.setdefault(n, _Inert(n))
+    for n in ("jax", "jax.numpy", "torchvision", "torchvision.models"):
+        sys.modules[n] = _Inert(n)
+    import lat_sm2_model as LM  # noqa: E402
+    # The script imports two classifier-guidance classes its lat_sm2_model no longer defines (an ImportError in the reference
+    # itself); the sampling path never touches them, so the import is satisfied with inert names.
+    for n in ("ClwithTime2", "ClwithTime3"):
+        if not hasattr(LM, n):
+            setattr(LM, n, type(n, (), {}))
+    import train_poly_unet_cont as TP  # noqa: E402  (reference script module)
+    out = {}
+    for tag, noise_obs, pc in (("nobs1_pc1", True, True), ("nobs0_pc0", False, False)):
+        pae = {k: synth.fill_module_(ResAE(POLY_ENC, POLY_DEC, 32, 64, 3).eval()) for k in "01"}
+        score = synth.fill_module_(Unet(dim=8, channels=2, dim_mults=(1, 2, 2, 2)).eval())
+        imgs = {"m" + k: torch.from_numpy(inp(f"cond.{tag}.p{k}", (3, 3, 32, 32), 0.25) + 0.5) for k in "01"}
+        shown = []
+        TP.plt.imshow = lambda a, _s=shown: _s.append(np.asarray(a).copy())
+        with _Noise(0xF1 + int(pc)) as nz:
+            TP.evaluate([(imgs, torch.zeros(3, dtype=torch.long))], pae, score, 1, 64, "vp", 9, "cpu", "", {"image": "x"}, "01", T=1, beta_0=0.1, beta_1=5.0,
+                        N=20, eps=1e-3, noise_obs=noise_obs, vae_type="AE", pc=pc, n_steps=1, target_snr=0.16)
+        kinds = [k for k, _ in nz.log]
+        per = 2 if pc else 1
+        # draw order: 2 normals (unused z), randn prior, 20*per randn_like (unconditional), loss_fn draws, 1 normal (cond z0), 20*per randn_like
+        assert kinds[2] == "randn" and kinds[-(20 * per) - 1] == "normal", kinds
+        out[f"{tag}_unc_prior"] = nz.log[2][1]
+        out[f"{tag}_unc_noise"] = np.stack([a for _, a in nz.log[3:3 + 20 * per]])
+        out[f"{tag}_cond_z0"] = nz.log[-(20 * per) - 1][1]
+        out[f"{tag}_cond_noise"] = np.stack([a for _, a in nz.log[-(20 * per):]])
+        out[f"{tag}_imgs"] = np.stack([imgs["m" + k].numpy() for k in "01"])
+        out[f"{tag}_unc_img"], out[f"{tag}_cond_img"] = shown[0], shown[1]
+        print(tag, "draws", len(nz.log), "images", [s.shape for s in shown])
+    save("conditional.npz", **out)
+
+
+if __name__ == "__main__" and "alt" in sys.argv[1:]:
+    alt_sampler_cases()
+if __name__ == "__main__" and "cond" in sys.argv[1:]:
+    conditional_cases()

@@ -126,3 +126,15 @@ def test_unet_openai_plan_matches_reference(golden, name, with_z):
     plan = planref.RefPlan(3, cfg, x.shape[0], sd, z_ld=int(with_z))
     y = plan.run_aux(x, t, z if with_z else None, want.shape)
     assert_close(y, want, 1e-5, 1e-5 * np.abs(want).max(), name)
+
+
+@pytest.mark.parametrize("tag,n_mod,size_z", [("mlp_small", 2, 16), ("mlp_poly5", 5, 64)])
+def test_mlp_score_plan(golden, tag, n_mod, size_z):
+    """LSMPoly64_sm as seven GEMM(+bias+softplus) ops: packing and tables checked on the host interpreter."""
+    g = golden("alt_samplers.npz")
+    sd = synth.fill_state_dict(arch.mlp_state_shapes(n_mod, size_z))
+    assert planref.specs(4, [n_mod, size_z]) == [(k, int(np.prod(s))) for k, s in arch.mlp_entries(n_mod, size_z)]
+    x = g[f"{tag}_x"]
+    plan = planref.RefPlan(4, [n_mod, size_z], x.shape[0], sd)
+    y = plan.run(x, None, x.shape)
+    assert_close(y, g[f"{tag}_y"], 1e-5, 1e-5 * np.abs(g[f"{tag}_y"]).max(), tag)
