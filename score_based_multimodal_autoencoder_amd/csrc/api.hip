@@ -274,19 +274,19 @@ int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, flo
   if (e) return fail(e);
   HIPCHK(hipStreamSynchronize(st));
   const size_t nops = m->plan.ops.size();
-  std::vector<hipEvent_t> ev(nops + 1);
+  std::vector<hipEvent_t> ev(2 * nops);
   for (auto& x : ev) HIPCHK(hipEventCreate(&x));
   for (int r = 0; r < reps; ++r) {
     if (m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipEventRecord(ev[0], st));
     for (size_t i = 0; i < nops; ++i) {
+      arm_profile_events(ev[2 * i], ev[2 * i + 1]);            // events ride on the kernel's own dispatch: begin -> end of the kernel
       e = launch_op(m->dp, (int)i, in_dev, out_dev, st);
+      arm_profile_events(nullptr, nullptr);
       if (e) return fail(e);
-      HIPCHK(hipEventRecord(ev[i + 1], st));
     }
     HIPCHK(hipStreamSynchronize(st));
     for (size_t i = 0; i < nops; ++i) {
-      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
       const int k = m->plan.ops[i].kind;
       if (k < n_kinds) { ms_by_kind[k] += ms / reps; if (r == 0) launches_by_kind[k] += 1; }
     }

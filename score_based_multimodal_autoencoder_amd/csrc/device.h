@@ -86,6 +86,7 @@ void launch_fill_time(float* t_out, const float* timesteps, const int* step_coun
 void launch_advance(int* step_counter, hipStream_t st);
 void launch_fill_normal(float* out, long long n_per_sample, int B, unsigned long long seed, unsigned long long sample_offset,
                         unsigned step, unsigned draw, float scale, hipStream_t st);
+void arm_profile_events(hipEvent_t start, hipEvent_t stop);
 void launch_set_counter(int* step_counter, int value, hipStream_t st);
 void launch_axpy_noise(const StepArgs& a, float ca, float cb, float sdiv, unsigned mod_mask, int per_mod, hipStream_t st);
 void launch_renoise(const StepArgs& a, const float* z_obs, unsigned obs_mask, int per_mod, hipStream_t st);

@@ -14,6 +14,21 @@
 #include "plan.h"
 #include "device.h"
 
+#include <hip/hip_ext.h>
+
+// Profiling hook: when an event pair is armed (sbm_model_profile), the next launch carries it on its own dispatch packet, so
+// hipEventElapsedTime(start, stop) is the kernel's begin->end time (what rocprofv3 --kernel-trace reports), free of the
+// dispatch latency that a hipEventRecord pair around the launch would include.
+namespace sbm {
+thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+void arm_profile_events(hipEvent_t start, hipEvent_t stop) { g_prof_start = start; g_prof_stop = stop; }
+}
+#define SBM_KLAUNCH(kern, grid, block, shmem, st, ...)                                                                      \
+  do {                                                                                                                     \
+    if (sbm::g_prof_start) hipExtLaunchKernelGGL(kern, grid, block, shmem, st, sbm::g_prof_start, sbm::g_prof_stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kern, grid, block, shmem, st, __VA_ARGS__);                                                    \
+  } while (0)
+
 namespace sbm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -817,8 +832,8 @@ static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, 
   dim3 grid((unsigned)blocks), block(256);
   const bool gn = o.gn != 0;
 #define SBM_LAUNCH(BM_, BN_, NST_) \
-  do { if (gn) hipLaunchKernelGGL((seg_gemm<BM_, BN_, NST_, true>), grid, block, 0, st, g); \
-       else hipLaunchKernelGGL((seg_gemm<BM_, BN_, NST_, false>), grid, block, 0, st, g); } while (0)
+  do { if (gn) SBM_KLAUNCH((seg_gemm<BM_, BN_, NST_, true>), grid, block, 0, st, g); \
+       else SBM_KLAUNCH((seg_gemm<BM_, BN_, NST_, false>), grid, block, 0, st, g); } while (0)
   if (o.BM == 64 && o.BN == 64) SBM_LAUNCH(64, 64, 4);
   else if (o.BM == 128 && o.BN == 64) SBM_LAUNCH(128, 64, 4);
   else SBM_LAUNCH(128, 128, 3);
@@ -837,50 +852,50 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       d.B = o.B; d.H = o.in.H; d.W = o.in.W; d.C = o.in.C; d.ldi = o.in.ld; d.ldo = o.out.ld; d.cond_ld = o.cond_ld;
       d.lanes = o.in.C / 4 < 256 ? o.in.C / 4 : 256; d.spb = 256 / d.lanes;
       dim3 grid(o.in.H * o.in.W, ceil_div(o.B, d.spb));
-      hipLaunchKernelGGL(dwconv7_kernel, grid, dim3(256), 0, st, d);
+      SBM_KLAUNCH(dwconv7_kernel, grid, dim3(256), 0, st, d);
     } break;
     case OP_LINATTN: case OP_ATTN: {
       const AttnOp& o = op.at; AttnArgs a{};
       a.qkv = ws + o.qkv.off; a.out = ws + o.out.off; a.B = o.B; a.n = o.qkv.H * o.qkv.W; a.ldq = o.qkv.ld; a.ldo = o.out.ld; a.heads = o.heads; a.scale = o.scale;
       if (o.dh != 32) return "attention: dim_head must be 32";
       if (op.kind == OP_ATTN && a.n > 64) return "softmax attention: more than 64 positions";
-      if (op.kind == OP_LINATTN) hipLaunchKernelGGL(linattn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
-      else hipLaunchKernelGGL(attn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
+      if (op.kind == OP_LINATTN) SBM_KLAUNCH(linattn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
+      else SBM_KLAUNCH(attn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
     } break;
     case OP_GN_RES: {
       const GnResOp& o = op.gr; GnResArgs g{};
       g.u = ws + o.u.off; g.x = ws + o.x.off; g.out = ws + o.out.off; g.part = reinterpret_cast<const float2*>(ws + o.part_off);
       g.gamma = prm + o.gamma_off; g.beta = prm + o.beta_off; g.B = o.B; g.P = o.u.H * o.u.W; g.C = o.u.C;
       g.ldu = o.u.ld; g.ldx = o.x.ld; g.ldo = o.out.ld; g.nparts = o.nparts; g.inv_count = o.inv_count;
-      hipLaunchKernelGGL(gn_res_kernel, dim3(o.B), dim3(256), 0, st, g);
+      SBM_KLAUNCH(gn_res_kernel, dim3(o.B), dim3(256), 0, st, g);
     } break;
     case OP_SINUS: {
       const SinusOp& o = op.si; const int n = o.B * o.ld;
-      hipLaunchKernelGGL(sinus_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ws + plan.time_off, prm + o.freq_off, ws + o.out_off, o.B, o.dim, o.ld, o.cos_first);
+      SBM_KLAUNCH(sinus_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ws + plan.time_off, prm + o.freq_off, ws + o.out_off, o.B, o.dim, o.ld, o.cos_first);
     } break;
     case OP_NCHW_TO_PBC: {
       const CvtOp& o = op.cv; const long long n = (long long)o.out.H * o.out.W * o.B * o.out.C;
-      hipLaunchKernelGGL(nchw_to_pbc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ext_in, ws + o.out.off, o.B, o.C, o.Hn, o.Wn, o.pad_y, o.pad_x, o.out.H, o.out.W, o.out.ld, o.out.C);
+      SBM_KLAUNCH(nchw_to_pbc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ext_in, ws + o.out.off, o.B, o.C, o.Hn, o.Wn, o.pad_y, o.pad_x, o.out.H, o.out.W, o.out.ld, o.out.C);
     } break;
     case OP_BILINEAR: {
       const BilinearOp& o = op.bl; BilArgs a{};
       a.in = ws + o.in.off; a.out = ws + o.out.off; a.B = o.B; a.Hi = o.in.H; a.Wi = o.in.W; a.Ho = o.out.H; a.Wo = o.out.W; a.C = o.in.C; a.ldi = o.in.ld; a.ldo = o.out.ld; a.scale = o.scale;
       const long long n = (long long)a.Ho * a.Wo * a.B * (a.C / 4);
-      hipLaunchKernelGGL(bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+      SBM_KLAUNCH(bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     } break;
     case OP_GN32: {
       const Gn32Op& o = op.gn; Gn32Args a{};
       a.in = ws + o.in.off; a.out = ws + o.out.off; a.gamma = prm + o.gamma_off; a.beta = prm + o.beta_off;
       a.B = o.B; a.P = o.in.H * o.in.W; a.C = o.in.C; a.ldi = o.in.ld; a.ldo = o.out.ld; a.groups = o.groups; a.silu = o.silu;
       if (o.in.C % o.groups || o.in.C > 2048 || o.groups > 64) return "gn32: C must be a multiple of the group count and <= 2048";
-      if (o.in.C % (4 * o.groups)) hipLaunchKernelGGL(gn32_small_kernel, dim3(ceil_div(o.B * o.groups, 256)), dim3(256), 0, st, a);
-      else hipLaunchKernelGGL(gn32_kernel, dim3(o.B), dim3(256), 0, st, a);
+      if (o.in.C % (4 * o.groups)) SBM_KLAUNCH(gn32_small_kernel, dim3(ceil_div(o.B * o.groups, 256)), dim3(256), 0, st, a);
+      else SBM_KLAUNCH(gn32_kernel, dim3(o.B), dim3(256), 0, st, a);
     } break;
     case OP_ATTN_QKV: {
       const AttnQkvOp& o = op.aq; AttnQkvArgs a{};
       a.qkv = ws + o.qkv.off; a.out = ws + o.out.off; a.B = o.B; a.T = o.qkv.H * o.qkv.W; a.ldq = o.qkv.ld; a.ldo = o.out.ld; a.heads = o.heads; a.chh = o.chh; a.scale = o.scale;
       if (a.T > 64) return "attention: more than 64 positions";
-      hipLaunchKernelGGL(attn_qkv_kernel, dim3(o.B * o.heads), dim3(256), 0, st, a);
+      SBM_KLAUNCH(attn_qkv_kernel, dim3(o.B * o.heads), dim3(256), 0, st, a);
     } break;
     default: return "unknown op";
   }
