@@ -156,6 +156,8 @@ int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_de
 long sbm_debug_workspace_floats(const sbm_model* m);
 int sbm_debug_read_workspace(sbm_model* m, long off, long n, float* host);
 int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap);
+int sbm_debug_chain_sync(sbm_model* m, unsigned* out, int n_words);
+int sbm_debug_chain_stamps(sbm_model* m, int first, int count, unsigned long long* out_host);
 int sbm_debug_gemm_stamps(sbm_model* m, const float* in_dev, float* out_dev, int i, unsigned long long* stamps_host);
 int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps,
                           double* ms_per_op, double* flops_per_op, int n_ops);

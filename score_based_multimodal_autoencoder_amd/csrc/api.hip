@@ -25,6 +25,8 @@ struct sbm_model {
   float* d_params = nullptr;
   float* d_ws = nullptr;
   GemmCold* d_cold = nullptr;    // one per op (only the GEMM entries are meaningful)
+  ChainOp* d_chain_ops = nullptr; // one per op (filled for ops marked op.chain)
+  ChainSync* d_chain_sync = nullptr;
   const float* aux_persistent = nullptr;   // z_cond used by sbm_sampler_run (sbm_model_set_aux)
   DevPlan dp;
   // sampler scratch (score nets only)
@@ -95,6 +97,8 @@ void sbm_model_destroy(sbm_model* m) {
   if (m->d_params) (void)hipFree(m->d_params);
   if (m->d_ws) (void)hipFree(m->d_ws);
   if (m->d_cold) (void)hipFree(m->d_cold);
+  if (m->d_chain_ops) (void)hipFree(m->d_chain_ops);
+  if (m->d_chain_sync) (void)hipFree(m->d_chain_sync);
   if (m->d_score) (void)hipFree(m->d_score);
   if (m->d_norms) (void)hipFree(m->d_norms);
   if (m->d_counter) (void)hipFree(m->d_counter);
@@ -142,6 +146,32 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
       if (ge) { std::string msg = std::string(ge) + " (" + m->plan.ops[i].name + ")"; sbm_model_destroy(m); return fail("sbm_model_create: " + msg); }
     }
     if ((e = hipMemcpy(m->d_cold, cold.data(), sizeof(GemmCold) * nops, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(cold args)", e); }
+    // op table of the XCD-resident chain kernel (chain.hip)
+    bool any_chain = false;
+    std::vector<ChainOp> cops(nops);
+    for (size_t i = 0; i < nops; ++i) {
+      const Op& op = m->plan.ops[i];
+      std::memset(&cops[i], 0, sizeof(ChainOp));
+      if (!op.chain) continue;
+      any_chain = true;
+      cops[i].kind = op.kind;
+      if (op.kind == OP_GEMM) { cops[i].g = m->dp.hot[i]; cops[i].P = op.g.Hout * op.g.Wout; }
+      else if (op.kind == OP_DWCONV7) cops[i].d = make_dw_args(op.dw, m->d_params, m->d_ws);
+      else if (op.kind == OP_LINATTN || op.kind == OP_ATTN) cops[i].a = make_attn_args(op.at, m->d_ws);
+      else if (op.kind == OP_GN_RES) cops[i].r = make_gnres_args(op.gr, m->d_params, m->d_ws);
+      else { sbm_model_destroy(m); return fail("sbm_model_create: op kind cannot run in the chain kernel (" + op.name + ")"); }
+    }
+    if (any_chain) {
+      if ((e = hipMalloc(&m->d_chain_ops, sizeof(ChainOp) * nops)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(chain ops)", e); }
+      if ((e = hipMalloc(&m->d_chain_sync, sizeof(ChainSync))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(chain sync)", e); }
+      if ((e = hipMemcpy(m->d_chain_ops, cops.data(), sizeof(ChainOp) * nops, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(chain ops)", e); }
+      if ((e = hipMemset(m->d_chain_sync, 0, sizeof(ChainSync))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemset(chain sync)", e); }
+      int dev = 0, cus = 0;
+      (void)hipGetDevice(&dev);
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      m->dp.chain_ops = m->d_chain_ops; m->dp.chain_sync = m->d_chain_sync;
+      m->dp.chain_grid = cus > 0 && cus < 256 ? cus : 256;      // one workgroup per CU: all of them are resident together
+    }
   }
   if (kind == SBM_UNET || kind == SBM_UNET_OA) {
     const size_t sbytes = (size_t)batch * m->plan.out_C * m->plan.out_H * m->plan.out_W * sizeof(float);
@@ -205,9 +235,18 @@ int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_de
   if (!m || !in_dev || !out_dev) return fail("sbm_debug_forward_range: bad arguments");
   hipStream_t st = (hipStream_t)stream;
   if (first == 0 && m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
-  for (int i = first; i < last && i < (int)m->plan.ops.size(); ++i) {
-    const char* e = launch_op(m->dp, (int)i, in_dev, out_dev, st);
+  const int nops = (int)m->plan.ops.size();
+  for (int i = first; i < last && i < nops;) {
+    int n = 1;
+    const char* e;
+    if (m->plan.ops[i].chain) {                      // like run_plan: consecutive chain ops of the range share one launch
+      while (i + n < last && i + n < nops && m->plan.ops[i + n].chain) ++n;
+      e = launch_chain(m->dp, i, n, st);
+    } else {
+      e = launch_op(m->dp, i, in_dev, out_dev, st);
+    }
     if (e) return fail(e);
+    i += n;
   }
   HIPCHK(hipStreamSynchronize(st));
   return 0;
@@ -241,6 +280,34 @@ int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap) {
   return 0;
 }
 
+// chain-kernel synchronisation state (count[8], arrived, done, abort_flag, pad[5], bar[128], left[128]); all zero between launches
+int sbm_debug_chain_sync(sbm_model* m, unsigned* out, int n_words) {
+  if (!m || !out || n_words <= 0) return fail("sbm_debug_chain_sync: bad arguments");
+  std::memset(out, 0, sizeof(unsigned) * n_words);
+  if (!m->d_chain_sync) return 0;
+  HIPCHK(hipDeviceSynchronize());
+  const size_t n = sizeof(ChainSync) < sizeof(unsigned) * n_words ? sizeof(ChainSync) : sizeof(unsigned) * n_words;
+  HIPCHK(hipMemcpy(out, m->d_chain_sync, n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// run chain ops [first, first+count) in one launch with time stamps armed: out[0] = start, out[1+2k] = workgroup 0 of the first
+// cluster finished op k, out[2+2k] = its cluster passed the barrier behind op k (s_memtime ticks, ~2.4 GHz)
+int sbm_debug_chain_stamps(sbm_model* m, int first, int count, unsigned long long* out_host) {
+  if (!m || !out_host || count <= 0 || count > 256) return fail("sbm_debug_chain_stamps: bad arguments");
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 520));
+  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 520));
+  g_chain_dbg = d;
+  const char* e = launch_chain(m->dp, first, count, m->own);
+  g_chain_dbg = nullptr;
+  if (e) { (void)hipFree(d); return fail(e); }
+  HIPCHK(hipStreamSynchronize(m->own));
+  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (1 + 2 * count), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return 0;
+}
+
 // per-op variant of sbm_model_profile: ms_per_op[i], flops_per_op[i], grid_per_op[i] for i < n_ops
 int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, double* ms_per_op, double* flops_per_op, int n_ops) {
   if (!m || !in_dev || !out_dev || reps <= 0 || !ms_per_op) return fail("sbm_debug_profile_ops: bad arguments");
@@ -249,18 +316,18 @@ int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev,
   if (e) return fail(e);
   HIPCHK(hipStreamSynchronize(st));
   const size_t nops = m->plan.ops.size();
-  std::vector<hipEvent_t> ev(nops + 1);
+  std::vector<hipEvent_t> ev(2 * nops);
   for (auto& x : ev) HIPCHK(hipEventCreate(&x));
   for (int i = 0; i < n_ops; ++i) { ms_per_op[i] = 0; if (flops_per_op) flops_per_op[i] = i < (int)nops ? m->plan.ops[i].flops : 0; }
   for (int r = 0; r < reps; ++r) {
-    HIPCHK(hipEventRecord(ev[0], st));
     for (size_t i = 0; i < nops; ++i) {
+      arm_profile_events(ev[2 * i], ev[2 * i + 1]);
       e = launch_op(m->dp, (int)i, in_dev, out_dev, st);
+      arm_profile_events(nullptr, nullptr);
       if (e) return fail(e);
-      HIPCHK(hipEventRecord(ev[i + 1], st));
     }
     HIPCHK(hipStreamSynchronize(st));
-    for (size_t i = 0; i < nops && (int)i < n_ops; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[i], ev[i + 1])); ms_per_op[i] += ms / reps; }
+    for (size_t i = 0; i < nops && (int)i < n_ops; ++i) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); ms_per_op[i] += ms / reps; }
   }
   for (auto& x : ev) (void)hipEventDestroy(x);
   return 0;

@@ -1,0 +1,457 @@
+// chain.hip -- the XCD-resident chain kernel: a run of consecutive low-resolution ops of the score net (the 2x2 and 1x1
+// levels: ~50 of the 95 ops, each far too small to fill the chip) executed by ONE launch.
+//
+// Why it is possible: nothing in the network mixes samples, so a tile of 32 samples can be carried through any number of
+// layers by a fixed set of workgroups with no grid-wide synchronisation.  Why it is per XCD: an MI355X has 8 XCDs with
+// private L2s that are coherent only at kernel boundaries; data stored by one CU is visible to another CU of the SAME XCD
+// as soon as it has reached that L2 (measured: tools/xcd_sync_probe.hip -- plain stores + `s_waitcnt vmcnt(0)` on the
+// producer, `sc1` loads that bypass the consumer's L1; across XCDs the same sequence reads stale data).  So:
+//
+//   * every workgroup reads its XCC_ID and registers with the cluster of that XCD (membership is decided by where the
+//     hardware actually placed it, never assumed from blockIdx);
+//   * cluster c carries sample tiles c, c + nclusters, ... (B = 256 -> 8 tiles, one per XCD) through all ops of the run;
+//   * after each op the cluster's workgroups meet at a barrier on a per-XCD counter (~0.8 us, vs ~5 us for a kernel
+//     boundary plus the pipeline fill/drain of a tiny launch);
+//   * activations written inside the launch are read with sc1 loads; weights and tables with ordinary cached loads.
+//
+// A barrier that does not complete within ~0.2 s sets ChainSync::abort_flag and every workgroup leaves: the grid always drains.
+#include <hip/hip_ext.h>
+
+#include "device.h"
+
+namespace sbm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define DEVINL __device__ __forceinline__
+
+namespace {
+
+DEVINL float chain_act(int act, float v) {
+  switch (act) {
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_LRELU02: return v >= 0.f ? v : 0.2f * v;
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    case ACT_SILU: return v / (1.0f + expf(-v));
+    case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+    default: return v;
+  }
+}
+
+DEVINL unsigned xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
+
+// L1-bypassing loads (global_load ... sc1): data another CU of this XCD stored earlier in the same launch
+DEVINL float ld1(const float* p) { return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVINL float2 ld2(const float* p) {
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+DEVINL float4 ld4(const float* p) { const float2 a = ld2(p), b = ld2(p + 2); return make_float4(a.x, a.y, b.x, b.y); }
+
+DEVINL unsigned ctr_add(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVINL unsigned ctr_load(unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVINL void ctr_zero(unsigned* p) { (void)__hip_atomic_exchange(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+
+struct Ctx {
+  int tid, lane, wave;
+  int slot, cs;          // this workgroup's index within its cluster, cluster size
+  int b0, B;             // first sample of the tile being carried, batch size
+  float* smem; float2* mr; unsigned* flag;
+  unsigned* bar; unsigned gen; ChainSync* sync;
+};
+
+// Every wave first waits until its own stores have been acknowledged by L2 -- explicitly: __syncthreads() alone is a
+// workgroup-scope fence, which on this target does NOT wait for vmcnt (the waves of a workgroup share one L1) -- then one
+// thread announces the workgroup and polls the XCD's counter.
+DEVINL bool cluster_barrier(Ctx& c) {
+  c.gen += (unsigned)c.cs;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (c.tid == 0) {
+    ctr_add(c.bar, 1u);
+    unsigned spins = 0, ok = 1;
+    while (ctr_load(c.bar) < c.gen) {
+      if (++spins > SPIN_LIMIT || ctr_load(&c.sync->abort_flag)) { (void)__hip_atomic_exchange(&c.sync->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *c.flag = ok;
+  }
+  __syncthreads();
+  return *c.flag != 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM: unit = (output pixel, 32-column block) of the 32-sample tile; the 4 waves split the chunk list (K), operands go
+// straight from L2 to registers (lane (i, h) of v_mfma_f32_32x32x2_f32 takes k = 16 h + j for the j-th MFMA of a chunk, on
+// both operands), partial accumulators meet in LDS.  Same chunk tables, folded GroupNorm and epilogue as seg_gemm.
+// ------------------------------------------------------------------------------------------------
+struct Frag { float a[16], w[16]; };
+
+DEVINL void load_frag(Frag& f, const GemmHot& g, const int4 d, int arow, int brow, int fh) {
+  const bool s2 = (d.w & 1) != 0;
+  const float* ap = (s2 ? g.A2 : g.A) + d.x + (long long)arow * (s2 ? g.lda2 : g.lda) + 16 * fh;
+  const float* wp = (s2 ? g.W2 : g.W) + d.y + (long long)brow * (s2 ? g.Kp2 : g.Kp) + 16 * fh;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float2 v = ld2(ap + 2 * j); f.a[2 * j] = v.x; f.a[2 * j + 1] = v.y; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float4 v = *reinterpret_cast<const float4*>(wp + 4 * j); f.w[4 * j] = v.x; f.w[4 * j + 1] = v.y; f.w[4 * j + 2] = v.z; f.w[4 * j + 3] = v.w; }
+}
+
+DEVINL void chain_gemm(const GemmHot g, int P, Ctx& c) {
+  const GemmCold cold = *g.cold;
+  const int fi = c.lane & 31, fh = c.lane >> 5;
+  const int nblk = (cold.nstore + 31) >> 5;
+  const bool gn = cold.gn_part != nullptr;
+  float rr[16];
+  if (gn) {
+    const int r = c.tid & 31, pl = c.tid >> 5;                 // 8 threads per tile row
+    const int bb = min(c.b0 + r, c.B - 1);
+    double s = 0.0, q = 0.0;
+    for (int i = pl; i < cold.gn_nparts; i += 8) { const float2 v = ld2(reinterpret_cast<const float*>(cold.gn_part + (long long)i * c.B + bb)); s += (double)v.x; q += (double)v.y; }
+    double* red = reinterpret_cast<double*>(c.smem);           // [8][32][2]
+    red[(pl * 32 + r) * 2] = s; red[(pl * 32 + r) * 2 + 1] = q;
+    __syncthreads();
+    if (c.tid < 32) {
+      double ss = 0.0, qq = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { ss += red[(k * 32 + c.tid) * 2]; qq += red[(k * 32 + c.tid) * 2 + 1]; }
+      const double inv = (double)cold.gn_inv_count, mean = ss * inv;
+      double var = qq * inv - mean * mean;
+      var = var < 0.0 ? 0.0 : var;
+      c.mr[c.tid] = make_float2((float)mean, rsqrtf((float)var + 1e-5f));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) rr[r2] = c.mr[(r2 & 3) + 8 * (r2 >> 2) + 4 * fh].y;
+  }
+  const int arow = min(c.b0 + fi, c.B - 1);
+  const int units = P * nblk;
+  for (int u = c.slot; u < units; u += c.cs) {
+    const int p = u / nblk, nb = u - p * nblk, n0 = nb * 32;
+    const int4 hd = g.hdr[p];
+    const int4* __restrict__ dsc = g.desc + hd.x;
+    const int total = hd.y, n1 = gn ? hd.z : 0;
+    const int brow = min(n0 + fi, g.Npad - 1);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto run = [&](int lo, int hi) {
+      int i = lo + c.wave;
+      if (i >= hi) return;
+      Frag cur, nxt;
+      load_frag(cur, g, dsc[i], arow, brow, fh);
+      for (; i < hi; i += 4) {
+        const bool more = i + 4 < hi;
+        if (more) load_frag(nxt, g, dsc[i + 4], arow, brow, fh);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.a[j], cur.w[j], acc, 0, 0, 0);
+        if (more) cur = nxt;
+      }
+    };
+    if (gn) {
+      run(0, n1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= rr[r];
+      run(n1, total);
+    } else {
+      run(0, total);
+    }
+    float* red = c.smem;                                       // [4 waves][32 rows][33]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(c.wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * 33 + fi] = acc[r];
+    __syncthreads();
+    const int row = c.tid >> 3, c4 = (c.tid & 7) * 4;
+    const int n = n0 + c4, bb = c.b0 + row;
+    const bool ok = n < cold.nstore && bb < c.B;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = ((red[row * 33 + c4 + e] + red[(32 + row) * 33 + c4 + e]) + red[(64 + row) * 33 + c4 + e]) + red[(96 + row) * 33 + c4 + e];
+    float s = 0.f, q = 0.f;
+    if (ok) {
+      if (cold.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(cold.bias + (long long)p * cold.bias_pix_stride + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+      }
+      if (gn) {
+        const float4 gs = *reinterpret_cast<const float4*>(cold.gn_s + (long long)p * g.Npad + n);
+        const float4 gb = *reinterpret_cast<const float4*>(cold.gn_b1 + (long long)p * g.Npad + n);
+        const float2 mrv = c.mr[row]; const float mrs = mrv.x * mrv.y;
+        v[0] += gb.x - mrs * gs.x; v[1] += gb.y - mrs * gs.y; v[2] += gb.z - mrs * gs.z; v[3] += gb.w - mrs * gs.w;
+      }
+      if (cold.R) {
+        const float4 rv = ld4(cold.R + ((long long)hd.w * c.B + bb) * cold.ldr + n);
+        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = chain_act(cold.act, v[e]);
+      *reinterpret_cast<float4*>(g.out + ((long long)p * c.B + bb) * cold.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+      s = (v[0] + v[1]) + (v[2] + v[3]); q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    if (cold.stat_out) {
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+      if ((c.tid & 7) == 0 && bb < c.B) cold.stat_out[((long long)p * nblk + nb) * c.B + bb] = make_float2(s, q);
+    }
+    __syncthreads();                                           // red is reused by the next unit
+  }
+}
+
+// depthwise 7x7 + bias + time condition + GroupNorm partial per (pixel, sample); see dwconv7_kernel
+DEVINL void chain_dw(const DwArgs d, Ctx& c) {
+  const int P = d.H * d.W, npairs = P * 32;
+  const int sl = c.tid / d.lanes, cl = c.tid - sl * d.lanes;
+  float2* red = reinterpret_cast<float2*>(c.smem);
+  for (int base = 0; base < npairs; base += c.cs * d.spb) {
+    const int qi = base + c.slot * d.spb + sl;
+    const int p = qi >> 5, b = c.b0 + (qi & 31);
+    const bool active = sl < d.spb && qi < npairs && b < c.B;
+    float s = 0.f, q = 0.f;
+    if (active) {
+      const int oy = p / d.W, ox = p - oy * d.W;
+      const int ky0 = max(0, 3 - oy), ky1 = min(7, d.H + 3 - oy), kx0 = max(0, 3 - ox), kx1 = min(7, d.W + 3 - ox);
+      for (int c4 = cl; c4 * 4 < d.C; c4 += d.lanes) {
+        const int ch = c4 * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ky = ky0; ky < ky1; ++ky)
+          for (int kx = kx0; kx < kx1; ++kx) {
+            const int qp = (oy - 3 + ky) * d.W + (ox - 3 + kx);
+            const float4 x = ld4(d.in + ((long long)qp * d.B + b) * d.ldi + ch);
+            const float4 w = *reinterpret_cast<const float4*>(d.w + (ky * 7 + kx) * d.C + ch);
+            acc.x = fmaf(x.x, w.x, acc.x); acc.y = fmaf(x.y, w.y, acc.y); acc.z = fmaf(x.z, w.z, acc.z); acc.w = fmaf(x.w, w.w, acc.w);
+          }
+        const float4 bi = *reinterpret_cast<const float4*>(d.bias + ch);
+        acc.x += bi.x; acc.y += bi.y; acc.z += bi.z; acc.w += bi.w;
+        if (d.cond) {
+          const float4 cv = *reinterpret_cast<const float4*>(d.cond + (long long)b * d.cond_ld + ch);
+          acc.x += cv.x; acc.y += cv.y; acc.z += cv.z; acc.w += cv.w;
+        }
+        *reinterpret_cast<float4*>(d.out + ((long long)p * d.B + b) * d.ldo + ch) = acc;
+        s += acc.x + acc.y + acc.z + acc.w;
+        q += acc.x * acc.x + acc.y * acc.y + acc.z * acc.z + acc.w * acc.w;
+      }
+    }
+    if (d.stat) {
+      red[c.tid] = make_float2(s, q);
+      __syncthreads();
+      if (active && cl == 0) {
+        float ss = 0.f, qq = 0.f;
+        for (int i = 0; i < d.lanes; ++i) { ss += red[c.tid + i].x; qq += red[c.tid + i].y; }
+        d.stat[(long long)p * d.B + b] = make_float2(ss, qq);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// LinearAttention core, one wave per (sample, head); see linattn_kernel
+DEVINL void chain_linattn(const AttnArgs a, Ctx& c) {
+  float* my = c.smem + c.wave * 1120;
+  float (*ctx)[33] = reinterpret_cast<float (*)[33]>(my);
+  float (*qs)[32] = reinterpret_cast<float (*)[32]>(my + 32 * 33);
+  const int d = c.lane & 31, half = c.lane >> 5;
+  const int ntask = 32 * a.heads, hd = a.heads * 32;
+  const long long pstride = (long long)a.B * a.ldq;
+  for (int base = 0; base < ntask; base += c.cs * 4) {
+    const int t = base + c.slot * 4 + c.wave;
+    const int bi = c.b0 + t / a.heads, h = t % a.heads;
+    const bool active = t < ntask && bi < c.B;
+    const int b = min(bi, c.B - 1);
+    const float* qb = a.qkv + (long long)b * a.ldq + h * 32;
+    float kmax = -INFINITY;
+    for (int i = half; i < a.n; i += 2) kmax = fmaxf(kmax, ld1(qb + i * pstride + hd + d));
+    kmax = fmaxf(kmax, __shfl_xor(kmax, 32));
+    float ksum = 0.f;
+    for (int i = half; i < a.n; i += 2) ksum += expf(ld1(qb + i * pstride + hd + d) - kmax);
+    ksum += __shfl_xor(ksum, 32);
+    const float kinv = 1.0f / ksum;
+    float cc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cc[e] = 0.f;
+    for (int i = 0; i < a.n; ++i) {
+      const float kv = expf(ld1(qb + i * pstride + hd + d) - kmax) * kinv;
+      const float* vrow = qb + i * pstride + 2 * hd + half * 16;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float2 vv = ld2(vrow + 2 * e); cc[2 * e] = fmaf(kv, vv.x, cc[2 * e]); cc[2 * e + 1] = fmaf(kv, vv.y, cc[2 * e + 1]); }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ctx[d][half * 16 + e] = cc[e];
+    __syncthreads();
+    float col[32];
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) col[dd] = ctx[dd][d];
+    for (int i0 = 0; i0 < a.n; i0 += 2) {
+      const int i = i0 + half;
+      const bool ok = i < a.n;
+      const float qv = ok ? ld1(qb + i * pstride + d) : 0.f;
+      float m = qv;
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      const float e = expf(qv - m);
+      float s = e;
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+      qs[half][d] = e / s * a.scale;
+      __syncthreads();
+      float o = 0.f;
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) o = fmaf(col[dd], qs[half][dd], o);
+      if (ok && active) a.out[((long long)i * a.B + b) * a.ldo + h * 32 + d] = o;
+      __syncthreads();
+    }
+  }
+}
+
+// softmax attention core, n <= 16 inside the chain; one wave per (sample, head); see attn_kernel
+DEVINL void chain_attn(const AttnArgs a, Ctx& c) {
+  float* my = c.smem + c.wave * 1088;
+  float (*sk)[17] = reinterpret_cast<float (*)[17]>(my);
+  float (*sv)[17] = reinterpret_cast<float (*)[17]>(my + 32 * 17);
+  const int ntask = 32 * a.heads, hd = a.heads * 32;
+  const long long pstride = (long long)a.B * a.ldq;
+  for (int base = 0; base < ntask; base += c.cs * 4) {
+    const int t = base + c.slot * 4 + c.wave;
+    const int bi = c.b0 + t / a.heads, h = t % a.heads;
+    const bool active = t < ntask && bi < c.B;
+    const int b = min(bi, c.B - 1);
+    const float* qb = a.qkv + (long long)b * a.ldq + h * 32;
+    for (int idx = c.lane; idx < 32 * a.n; idx += 64) {
+      const int j = idx >> 5, dd = idx & 31;
+      sk[dd][j] = ld1(qb + j * pstride + hd + dd); sv[dd][j] = ld1(qb + j * pstride + 2 * hd + dd);
+    }
+    __syncthreads();
+    if (c.lane < a.n) {
+      float q[32];
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) q[dd] = ld1(qb + c.lane * pstride + dd) * a.scale;
+      float m = -INFINITY;
+      for (int j = 0; j < a.n; ++j) { float tt = 0.f; for (int dd = 0; dd < 32; ++dd) tt = fmaf(q[dd], sk[dd][j], tt); m = fmaxf(m, tt); }
+      float s = 0.f, o[32];
+#pragma unroll
+      for (int dd = 0; dd < 32; ++dd) o[dd] = 0.f;
+      for (int j = 0; j < a.n; ++j) {
+        float tt = 0.f; for (int dd = 0; dd < 32; ++dd) tt = fmaf(q[dd], sk[dd][j], tt);
+        const float e = expf(tt - m); s += e;
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) o[dd] = fmaf(e, sv[dd][j], o[dd]);
+      }
+      const float inv = 1.0f / s;
+      if (active)
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) a.out[((long long)c.lane * a.B + b) * a.ldo + h * 32 + dd] = o[dd] * inv;
+    }
+    __syncthreads();
+  }
+}
+
+// y = GroupNorm(1,C)(u) * gamma + beta + x, one workgroup per sample; see gn_res_kernel
+DEVINL void chain_gn_res(const GnResArgs g, Ctx& c) {
+  double* rs = reinterpret_cast<double*>(c.smem);              // [256] sums, [256] squares
+  double* rq = rs + 256;
+  for (int r = c.slot; r < 32; r += c.cs) {
+    const int b = c.b0 + r;
+    if (b >= c.B) break;
+    double s = 0.0, q = 0.0;
+    for (int i = c.tid; i < g.nparts; i += 256) { const float2 v = ld2(reinterpret_cast<const float*>(g.part + (long long)i * g.B + b)); s += v.x; q += v.y; }
+    rs[c.tid] = s; rq[c.tid] = q;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) { if (c.tid < o) { rs[c.tid] += rs[c.tid + o]; rq[c.tid] += rq[c.tid + o]; } __syncthreads(); }
+    const double mean_d = rs[0] * (double)g.inv_count;
+    double var = rq[0] * (double)g.inv_count - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const int c4n = g.C / 4;
+    for (int idx = c.tid; idx < g.P * c4n; idx += 256) {
+      const int p = idx / c4n, ch = (idx - p * c4n) * 4;
+      const long long row = (long long)p * g.B + b;
+      const float4 u = ld4(g.u + row * g.ldu + ch);
+      const float4 x = ld4(g.x + row * g.ldx + ch);
+      const float4 ga = *reinterpret_cast<const float4*>(g.gamma + ch);
+      const float4 be = *reinterpret_cast<const float4*>(g.beta + ch);
+      float4 y;
+      y.x = ((u.x - mean) * rstd) * ga.x + be.x + x.x; y.y = ((u.y - mean) * rstd) * ga.y + be.y + x.y;
+      y.z = ((u.z - mean) * rstd) * ga.z + be.z + x.z; y.w = ((u.w - mean) * rstd) * ga.w + be.w + x.w;
+      *reinterpret_cast<float4*>(g.out + row * g.ldo + ch) = y;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void chain_kernel(const ChainOp* __restrict__ ops, int count, ChainSync* sync, int B, unsigned long long* dbg) {
+  __shared__ __attribute__((aligned(16))) float smem[4608];
+  __shared__ float2 mr[32];
+  __shared__ unsigned info[8];
+  Ctx c;
+  c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
+  c.smem = smem; c.mr = mr; c.flag = &info[7]; c.sync = sync; c.B = B; c.gen = 0;
+  const unsigned xcc = xcc_id();
+  // ---- registration: which XCD am I on, who else is here ----
+  if (c.tid == 0) {
+    const unsigned slot = ctr_add(&sync->count[xcc], 1u);
+    ctr_add(&sync->arrived, 1u + (slot >> 31));                // issued only after `slot` has come back
+    unsigned spins = 0, ok = 1;
+    while (ctr_load(&sync->arrived) < gridDim.x) {
+      if (++spins > SPIN_LIMIT) { (void)__hip_atomic_exchange(&sync->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    unsigned nact = 0, ci = 0;
+    for (unsigned i = 0; i < 8; ++i) { const unsigned n = ctr_load(&sync->count[i]); if (n) { if (i < xcc) ++ci; ++nact; } }
+    info[0] = slot; info[1] = ctr_load(&sync->count[xcc]); info[2] = ci; info[3] = nact; info[4] = ok;
+  }
+  __syncthreads();
+  c.slot = (int)info[0]; c.cs = (int)info[1];
+  const int ci = (int)info[2], nact = (int)info[3];
+  bool alive = info[4] != 0;
+  c.bar = &sync->bar[xcc * 16];
+  const int tiles = (B + 31) >> 5;
+  const bool stamp = dbg && ci == 0 && c.slot == 0 && c.tid == 0;
+  if (stamp) dbg[0] = __builtin_amdgcn_s_memtime();
+  for (int tile = ci; alive && tile < tiles; tile += nact) {
+    c.b0 = tile * 32;
+    for (int k = 0; alive && k < count; ++k) {
+      const ChainOp& op = ops[k];
+      switch (op.kind) {
+        case OP_GEMM: chain_gemm(op.g, op.P, c); break;
+        case OP_DWCONV7: chain_dw(op.d, c); break;
+        case OP_LINATTN: chain_linattn(op.a, c); break;
+        case OP_ATTN: chain_attn(op.a, c); break;
+        case OP_GN_RES: chain_gn_res(op.r, c); break;
+        default: break;
+      }
+      if (stamp && tile == ci) dbg[1 + 2 * k] = __builtin_amdgcn_s_memtime();        // this workgroup finished op k
+      alive = cluster_barrier(c);
+      if (stamp && tile == ci) dbg[2 + 2 * k] = __builtin_amdgcn_s_memtime();        // the whole cluster has
+    }
+  }
+  // ---- leave: the last workgroup of the XCD clears its barrier counter, the last of the grid the registration ----
+  if (c.tid == 0) {
+    if (ctr_add(&sync->left[xcc * 16], 1u) == (unsigned)c.cs - 1u) { ctr_zero(&sync->bar[xcc * 16]); ctr_zero(&sync->left[xcc * 16]); }
+    if (ctr_add(&sync->done, 1u) == gridDim.x - 1u) {
+      for (int i = 0; i < 8; ++i) ctr_zero(&sync->count[i]);
+      ctr_zero(&sync->arrived); ctr_zero(&sync->done);
+    }
+  }
+}
+
+unsigned long long* g_chain_dbg = nullptr;   // diagnostics only (sbm_debug_chain_stamps)
+
+const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st) {
+  if (!dp.chain_ops || !dp.chain_sync) return "chain kernel: no op table";
+  const Plan& plan = *dp.plan;
+  for (int i = first; i < first + count; ++i) {
+    const Op& op = plan.ops[i];
+    if (!op.chain) return "chain kernel: op is not marked for the chain";
+    if (op.kind == OP_GEMM && (op.g.a_ext || op.g.out_nchw)) return "chain kernel: external operands are not supported";
+    if ((op.kind == OP_LINATTN || op.kind == OP_ATTN) && op.at.dh != 32) return "attention: dim_head must be 32";
+    if (op.kind == OP_ATTN && op.at.qkv.H * op.at.qkv.W > 16) return "chain kernel: softmax attention over more than 16 positions";
+  }
+  const ChainOp* ops = dp.chain_ops + first;
+  if (g_prof_start) hipExtLaunchKernelGGL(chain_kernel, dim3(dp.chain_grid), dim3(256), 0, st, g_prof_start, g_prof_stop, 0, ops, count, dp.chain_sync, plan.B, g_chain_dbg);
+  else hipLaunchKernelGGL(chain_kernel, dim3(dp.chain_grid), dim3(256), 0, st, ops, count, dp.chain_sync, plan.B, g_chain_dbg);
+  return nullptr;
+}
+
+}  // namespace sbm

@@ -30,6 +30,28 @@ struct GemmHot {
   unsigned long long* dbg;              // diagnostic cycle stamps (null in production)
 };
 
+struct DwArgs {
+  const float* in; float* out; const float* w; const float* bias; const float* cond; float2* stat;
+  int B, H, W, C, ldi, ldo, cond_ld, lanes, spb;   // lanes = threads per sample, spb = samples per block
+};
+struct AttnArgs { const float* qkv; float* out; int B, n, ldq, ldo, heads; float scale; };
+struct GnResArgs { const float* u; const float* x; float* out; const float2* part; const float* gamma; const float* beta; int B, P, C, ldu, ldx, ldo, nparts; float inv_count; };
+DwArgs make_dw_args(const DwOp& o, const float* prm, float* ws);
+AttnArgs make_attn_args(const AttnOp& o, float* ws);
+GnResArgs make_gnres_args(const GnResOp& o, const float* prm, float* ws);
+
+// ---- XCD-resident chain kernel (chain.hip): a run of low-resolution ops executed by ONE launch ----
+struct ChainOp { int kind; int P; int pad0, pad1; GemmHot g; DwArgs d; AttnArgs a; GnResArgs r; };
+struct ChainSync {
+  unsigned count[8];        // workgroups registered per XCD
+  unsigned arrived;         // total registered
+  unsigned done;            // workgroups that finished (the last one resets the registration state)
+  unsigned abort_flag;      // set when a barrier timed out (results are then invalid)
+  unsigned pad[5];
+  unsigned bar[8 * 16];     // one barrier counter per XCD, 64 bytes apart
+  unsigned left[8 * 16];    // workgroups of the XCD that have finished (the last one resets bar)
+};
+
 // A plan resolved against its device arenas.
 struct DevPlan {
   const Plan* plan = nullptr;
@@ -37,7 +59,11 @@ struct DevPlan {
   float* ws = nullptr;          // device workspace arena
   std::vector<GemmHot> hot;     // per op (valid for OP_GEMM)
   const float* aux = nullptr;   // per-call auxiliary input (UNetModel z), copied into ws[plan.aux_off] by run_plan
+  const ChainOp* chain_ops = nullptr;   // device array, one entry per plan op (filled for chain ops)
+  ChainSync* chain_sync = nullptr;
+  int chain_grid = 256;
 };
+const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st);
 const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, float* ws, const GemmCold* cold_dev, GemmHot* hot, GemmCold* cold);
 
 // Enqueue every op of the plan on `st`.  Returns nullptr or a static error string.  No allocation, no
@@ -46,6 +72,7 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
 const char* launch_op(const DevPlan& dp, int op_index, const float* ext_in, float* ext_out, hipStream_t st);
 
 extern unsigned long long* g_gemm_dbg;
+extern unsigned long long* g_chain_dbg;
 
 // SDE description shared by the step kernels (mirrors oracle/sde.py SDECfg)
 struct SdeParams {
@@ -87,6 +114,7 @@ void launch_advance(int* step_counter, hipStream_t st);
 void launch_fill_normal(float* out, long long n_per_sample, int B, unsigned long long seed, unsigned long long sample_offset,
                         unsigned step, unsigned draw, float scale, hipStream_t st);
 void arm_profile_events(hipEvent_t start, hipEvent_t stop);
+extern thread_local hipEvent_t g_prof_start, g_prof_stop;   // armed by arm_profile_events (kernels.hip)
 void launch_set_counter(int* step_counter, int value, hipStream_t st);
 void launch_axpy_noise(const StepArgs& a, float ca, float cb, float sdiv, unsigned mod_mask, int per_mod, hipStream_t st);
 void launch_renoise(const StepArgs& a, const float* z_obs, unsigned obs_mask, int per_mod, hipStream_t st);

@@ -451,10 +451,6 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
 // ------------------------------------------------------------------------------------------------
 // depthwise 7x7 + bias + time condition, GroupNorm partials per (pixel, sample)
 // ------------------------------------------------------------------------------------------------
-struct DwArgs {
-  const float* in; float* out; const float* w; const float* bias; const float* cond; float2* stat;
-  int B, H, W, C, ldi, ldo, cond_ld, lanes, spb;   // lanes = threads per sample, spb = samples per block
-};
 
 __global__ __launch_bounds__(256) void dwconv7_kernel(const DwArgs d) {
   __shared__ float2 red[256];
@@ -502,7 +498,6 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const DwArgs d) {
 // LinearAttention core (unet_model.py:169-175): one wave per (sample, head); lane = head dim d,
 // the two 32-lane halves take alternate pixels.
 // ------------------------------------------------------------------------------------------------
-struct AttnArgs { const float* qkv; float* out; int B, n, ldq, ldo, heads; float scale; };
 
 __global__ __launch_bounds__(64) void linattn_kernel(const AttnArgs a) {
   __shared__ float ctx[32][33];
@@ -596,7 +591,6 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
 // ------------------------------------------------------------------------------------------------
 // y = GroupNorm(1,C)(u) * gamma + beta + x   -- one workgroup per sample
 // ------------------------------------------------------------------------------------------------
-struct GnResArgs { const float* u; const float* x; float* out; const float2* part; const float* gamma; const float* beta; int B, P, C, ldu, ldx, ldo, nparts; float inv_count; };
 
 __global__ __launch_bounds__(256) void gn_res_kernel(const GnResArgs g) {
   __shared__ double rs[256], rq[256];
@@ -798,7 +792,7 @@ const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, 
   if ((long long)o.B * (o.a.ld > o.a2.ld ? o.a.ld : o.a2.ld) >= (1LL << 30) || (long long)o.Npad * (o.Kp > o.Kp2 ? o.Kp : o.Kp2) >= (1LL << 30))
     return "seg_gemm: operand plane too large for 32-bit lane offsets";
   if (o.hdr_off < 0 || o.desc_off < 0 || plan.ident_off < 0) return "seg_gemm: chunk tables missing";
-  if (!((o.BM == 64 && o.BN == 64) || (o.BM == 128 && o.BN == 64) || (o.BM == 128 && o.BN == 128))) return "seg_gemm: unsupported tile";
+  if (!((o.BM == 64 && o.BN == 64) || (o.BM == 128 && o.BN == 64) || (o.BM == 128 && o.BN == 128) || (o.BM == 32 && o.BN == 32))) return "seg_gemm: unsupported tile";
   GemmHot h{};
   h.A = o.a_ext ? nullptr : ws + o.a.off;            // external input patched at launch
   h.A2 = o.has2 ? ws + o.a2.off : nullptr;
@@ -823,6 +817,27 @@ const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, 
   return nullptr;
 }
 
+DwArgs make_dw_args(const DwOp& o, const float* prm, float* ws) {
+  DwArgs d{};
+  d.in = ws + o.in.off; d.out = ws + o.out.off; d.w = prm + o.w_off; d.bias = prm + o.bias_off;
+  d.cond = o.has_cond ? ws + o.cond_off : nullptr; d.stat = o.stat_off >= 0 ? reinterpret_cast<float2*>(ws + o.stat_off) : nullptr;
+  d.B = o.B; d.H = o.in.H; d.W = o.in.W; d.C = o.in.C; d.ldi = o.in.ld; d.ldo = o.out.ld; d.cond_ld = o.cond_ld;
+  d.lanes = o.in.C / 4 < 256 ? o.in.C / 4 : 256; d.spb = 256 / d.lanes;
+  return d;
+}
+AttnArgs make_attn_args(const AttnOp& o, float* ws) {
+  AttnArgs a{};
+  a.qkv = ws + o.qkv.off; a.out = ws + o.out.off; a.B = o.B; a.n = o.qkv.H * o.qkv.W; a.ldq = o.qkv.ld; a.ldo = o.out.ld; a.heads = o.heads; a.scale = o.scale;
+  return a;
+}
+GnResArgs make_gnres_args(const GnResOp& o, const float* prm, float* ws) {
+  GnResArgs g{};
+  g.u = ws + o.u.off; g.x = ws + o.x.off; g.out = ws + o.out.off; g.part = reinterpret_cast<const float2*>(ws + o.part_off);
+  g.gamma = prm + o.gamma_off; g.beta = prm + o.beta_off; g.B = o.B; g.P = o.u.H * o.u.W; g.C = o.u.C;
+  g.ldu = o.u.ld; g.ldx = o.x.ld; g.ldo = o.out.ld; g.nparts = o.nparts; g.inv_count = o.inv_count;
+  return g;
+}
+
 static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, float* ext_out, hipStream_t st) {
   if (o.a_ext) g.A = ext_in + o.a.off;
   if (o.out_nchw) g.out = ext_out;
@@ -843,30 +858,23 @@ static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, 
 
 const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ext_out, hipStream_t st) {
   const Plan& plan = *dp.plan; const Op& op = plan.ops[idx]; const float* prm = dp.prm; float* ws = dp.ws;
+  if (op.chain) return launch_chain(dp, idx, 1, st);
   switch (op.kind) {
     case OP_GEMM: return launch_gemm(op.g, dp.hot[idx], ext_in, ext_out, st);
     case OP_DWCONV7: {
-      const DwOp& o = op.dw; DwArgs d{};
-      d.in = ws + o.in.off; d.out = ws + o.out.off; d.w = prm + o.w_off; d.bias = prm + o.bias_off;
-      d.cond = o.has_cond ? ws + o.cond_off : nullptr; d.stat = o.stat_off >= 0 ? reinterpret_cast<float2*>(ws + o.stat_off) : nullptr;
-      d.B = o.B; d.H = o.in.H; d.W = o.in.W; d.C = o.in.C; d.ldi = o.in.ld; d.ldo = o.out.ld; d.cond_ld = o.cond_ld;
-      d.lanes = o.in.C / 4 < 256 ? o.in.C / 4 : 256; d.spb = 256 / d.lanes;
+      const DwOp& o = op.dw; const DwArgs d = make_dw_args(o, prm, ws);
       dim3 grid(o.in.H * o.in.W, ceil_div(o.B, d.spb));
       SBM_KLAUNCH(dwconv7_kernel, grid, dim3(256), 0, st, d);
     } break;
     case OP_LINATTN: case OP_ATTN: {
-      const AttnOp& o = op.at; AttnArgs a{};
-      a.qkv = ws + o.qkv.off; a.out = ws + o.out.off; a.B = o.B; a.n = o.qkv.H * o.qkv.W; a.ldq = o.qkv.ld; a.ldo = o.out.ld; a.heads = o.heads; a.scale = o.scale;
+      const AttnOp& o = op.at; const AttnArgs a = make_attn_args(o, ws);
       if (o.dh != 32) return "attention: dim_head must be 32";
       if (op.kind == OP_ATTN && a.n > 64) return "softmax attention: more than 64 positions";
       if (op.kind == OP_LINATTN) SBM_KLAUNCH(linattn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
       else SBM_KLAUNCH(attn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
     } break;
     case OP_GN_RES: {
-      const GnResOp& o = op.gr; GnResArgs g{};
-      g.u = ws + o.u.off; g.x = ws + o.x.off; g.out = ws + o.out.off; g.part = reinterpret_cast<const float2*>(ws + o.part_off);
-      g.gamma = prm + o.gamma_off; g.beta = prm + o.beta_off; g.B = o.B; g.P = o.u.H * o.u.W; g.C = o.u.C;
-      g.ldu = o.u.ld; g.ldx = o.x.ld; g.ldo = o.out.ld; g.nparts = o.nparts; g.inv_count = o.inv_count;
+      const GnResOp& o = op.gr; const GnResArgs g = make_gnres_args(o, prm, ws);
       SBM_KLAUNCH(gn_res_kernel, dim3(o.B), dim3(256), 0, st, g);
     } break;
     case OP_SINUS: {
@@ -908,9 +916,17 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
     if (hipMemcpyAsync(dp.ws + plan.time_off, t_dev, sizeof(float) * plan.B, hipMemcpyDeviceToDevice, st) != hipSuccess) return "time copy failed";
   if (plan.aux_off >= 0 && dp.aux)
     if (hipMemcpyAsync(dp.ws + plan.aux_off, dp.aux, sizeof(float) * plan.B * plan.aux_C, hipMemcpyDeviceToDevice, st) != hipSuccess) return "aux copy failed";
-  for (int i = 0; i < (int)plan.ops.size(); ++i) {
-    const char* e = launch_op(dp, i, ext_in, ext_out, st);
+  for (int i = 0; i < (int)plan.ops.size();) {
+    int n = 1;
+    const char* e;
+    if (plan.ops[i].chain) {                        // a maximal run of chain ops is ONE launch
+      while (i + n < (int)plan.ops.size() && plan.ops[i + n].chain) ++n;
+      e = launch_chain(dp, i, n, st);
+    } else {
+      e = launch_op(dp, i, ext_in, ext_out, st);
+    }
     if (e) return e;
+    i += n;
   }
   if (hipGetLastError() != hipSuccess) return "kernel launch failed";
   return nullptr;

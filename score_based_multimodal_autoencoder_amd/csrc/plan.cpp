@@ -7,8 +7,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <stdexcept>
 
 namespace sbm {
@@ -193,10 +195,19 @@ class Builder {
   }
 
   // ---- workspace allocator: first-fit free list, blocks rounded to 64 floats (256 B) ----
-  int64_t ws_alloc(int64_t n) {
+  // `pin`: the block is taken from fresh memory and never returned to the free list.  Buffers touched by ops of the chain
+  // kernel need this: its clusters (one per XCD, one sample tile each) run through the op list independently, so memory
+  // may not be recycled between ops with different layouts -- a fast cluster would overwrite what a slow one still reads.
+  int64_t ws_alloc(int64_t n, bool pin = false) {
     // +32 floats of slack: the GEMM kernel reads whole 32-float K chunks, so the last row of a tensor whose
     // channel count is not a multiple of 32 is read up to 28 floats past its end (times zero weights)
     n = (n + 32 + 63) / 64 * 64;
+    if (pin) {
+      int64_t off = plan->ws_floats;
+      plan->ws_floats += n;
+      sizes[off] = n; pinned.insert(off);
+      return off;
+    }
     for (size_t i = 0; i < free_list.size(); ++i) {
       if (free_list[i].n >= n) {
         int64_t off = free_list[i].off;
@@ -214,6 +225,7 @@ class Builder {
   void ws_free(int64_t off) {
     auto it = sizes.find(off);
     if (it == sizes.end()) throw std::runtime_error("plan: double free");
+    if (pinned.count(off)) { sizes.erase(it); pinned.erase(off); return; }
     Block b{off, it->second};
     sizes.erase(it);
     // insert sorted + coalesce
@@ -228,14 +240,17 @@ class Builder {
     }
   }
   std::map<int64_t, int64_t> sizes;
+  std::set<int64_t> pinned;
+  bool in_chain(int P) const { return chain_pix > 0 && P <= chain_pix; }
 
   View new_act(int H, int W, int C) {
     View v; v.H = H; v.W = W; v.C = pad8(C); v.ld = v.C;
-    v.off = ws_alloc((int64_t)H * W * B * v.ld);
+    v.off = ws_alloc((int64_t)H * W * B * v.ld, in_chain(H * W));
     return v;
   }
   void free_act(const View& v) { ws_free(v.off); }
-  int64_t new_stats(int nparts) { return ws_alloc((int64_t)nparts * B * 2); }
+  int64_t new_stats(int nparts, bool pin = false) { return ws_alloc((int64_t)nparts * B * 2, pin); }
+  int chain_pix = 0;        // ops with P <= chain_pix are marked for the chain kernel
 
   // ---- tile choice ----
   static void choose_tile(int B, int P, int nstore, int* BM, int* BN) {
@@ -352,6 +367,7 @@ class Builder {
     g.act = s.act;
     const int P = s.Hout * s.Wout;
     choose_tile(B, P, nstore, &g.BM, &g.BN);
+    if (chain_pix > 0 && P <= chain_pix && !s.out_nchw) { op.chain = 1; g.BM = 32; g.BN = 32; }
     ConvResult res;
     if (s.out_nchw) {
       g.out_nchw = 1; g.crop_y = s.crop_y; g.crop_x = s.crop_x; g.Hn = s.Hn; g.Wn = s.Wn;
@@ -363,7 +379,7 @@ class Builder {
     if (s.want_stats) {
       const int ntiles = ceil_div(nstore, g.BN);
       res.stat_nparts = P * ntiles;
-      res.stat_off = g.stat_off = new_stats(res.stat_nparts);
+      res.stat_off = g.stat_off = new_stats(res.stat_nparts, op.chain != 0);
     }
     // flop accounting
     double taps_valid = 0;
@@ -391,10 +407,11 @@ BlockIO emit_convnext(Builder& b, const std::string& pre, const View& x, const C
                       bool has_time, int64_t cond_off, int cond_ld, bool want_out_stats, View* dest) {
   const int H = x.H, W = x.W, P = H * W;
   // depthwise 7x7 + bias + time condition -> h0, GroupNorm partials
-  View h0; h0.H = H; h0.W = W; h0.C = x.C; h0.ld = x.C; h0.off = b.ws_alloc((int64_t)P * b.B * h0.ld);
-  int64_t st0 = b.new_stats(P);
+  View h0; h0.H = H; h0.W = W; h0.C = x.C; h0.ld = x.C; h0.off = b.ws_alloc((int64_t)P * b.B * h0.ld, b.in_chain(P));
+  int64_t st0 = b.new_stats(P, b.in_chain(P));
   {
     Op& op = b.push(OP_DWCONV7, pre + "ds_conv");
+    if (b.chain_pix > 0 && P <= b.chain_pix) op.chain = 1;
     DwOp& d = op.dw; d.B = b.B; d.in = x; d.out = h0;
     const float* w = b.T(pre + "ds_conv.weight", (int64_t)cin * 49);
     std::vector<float> wp((size_t)49 * x.C, 0.f);
@@ -450,6 +467,7 @@ View emit_attention(Builder& b, const std::string& pre, const View& x, int c, in
   View att = b.new_act(H, W, hid);
   {
     Op& op = b.push(linear ? OP_LINATTN : OP_ATTN, pre + "fn.fn.core");
+    if (b.chain_pix > 0 && P <= b.chain_pix) op.chain = 1;
     AttnOp& a = op.at; a.B = b.B; a.qkv = rq.out; a.out = att; a.heads = 4; a.dh = 32; a.scale = 1.0f / std::sqrt(32.0f);
     b.plan->flops_dense += 2.0 * b.B * 4 * (linear ? 2.0 * 32 * 32 * P : 2.0 * 32 * (double)P * P);
     b.plan->flops_exec += 2.0 * b.B * 4 * (linear ? 2.0 * 32 * 32 * P : 2.0 * 32 * (double)P * P);
@@ -464,6 +482,7 @@ View emit_attention(Builder& b, const std::string& pre, const View& x, int c, in
     Builder::ConvResult ro = b.emit_conv(o);
     out = dest ? *dest : b.new_act(H, W, c);
     Op& op = b.push(OP_GN_RES, pre + "fn.fn.to_out.1+residual");
+    if (b.chain_pix > 0 && P <= b.chain_pix) op.chain = 1;
     GnResOp& g = op.gr; g.B = b.B; g.u = ro.out; g.x = x; g.out = out;
     g.part_off = ro.stat_off; g.nparts = ro.stat_nparts; g.inv_count = 1.0f / ((float)c * P);
     g.gamma_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.weight", c), c, nullptr, x.C));
@@ -484,10 +503,17 @@ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace
 
+int chain_pix_from_env() {
+  const char* e = std::getenv("SBM_CHAIN_PIX");
+  const int v = e ? std::atoi(e) : 4;
+  return v < 0 ? 0 : (v > 16 ? 16 : v);
+}
+
 bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Plan* plan) {
   try {
     std::vector<TensorSpec> specs = unet_tensor_specs(cfg);
     Builder b(plan, B, specs, tensors);
+    b.chain_pix = chain_pix_from_env();
     UnetDims d = unet_dims(cfg);
     const int n = (int)d.in_out.size();
     const int Hp = next_pow2(cfg.H), Wp = next_pow2(cfg.W);       // unet_model.py:276-284
@@ -589,7 +615,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       View dest; View* dp = nullptr;
       if (i >= 1) {
         // concat buffer [x_up (co) | h_i (co)], both padded to 8
-        View cb; cb.H = H; cb.W = W; cb.C = 2 * pad8(co); cb.ld = cb.C; cb.off = b.ws_alloc((int64_t)H * W * B * cb.ld);
+        View cb; cb.H = H; cb.W = W; cb.C = 2 * pad8(co); cb.ld = cb.C; cb.off = b.ws_alloc((int64_t)H * W * B * cb.ld, b.in_chain(H * W));
         cat[i] = cb;
         dest = cb; dest.off = cb.off + pad8(co); dest.C = pad8(co);
         dp = &dest;

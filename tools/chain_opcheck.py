@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Op-by-op: GPU (each op launched alone; chain ops through the chain kernel) vs the host plan interpreter."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import planref
+from score_based_multimodal_autoencoder_amd import _lib, arch, synth
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 67
+dim = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+c = dict(dim=dim, channels=2, dim_mults=(1, 2, 2, 2))
+sd = synth.fill_state_dict(arch.unet_state_shapes(**c))
+cfg = _lib.unet_cfg_ints(dim, 2, (1, 2, 2, 2), 8, 8)
+x = synth.noise(5, 1, (B, 2, 8, 8)); t = (np.abs(synth.noise(5, 2, (B,))) % 1.0).astype(np.float32)
+ref = planref.RefPlan(0, cfg, B, sd); eng = _lib.Engine(0, cfg, B, sd)
+L = _lib.lib(); n_ws = L.sbm_debug_workspace_floats(eng.h)
+xd, td = torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()
+out_d = torch.zeros(B, 2, 8, 8, device="cuda"); out_h = np.zeros((B, 2, 8, 8), np.float32)
+ws_ref = ref.workspace(); host = np.empty(n_ws, np.float32)
+STEP = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+for rep in range(1):
+  for i in range(0, ref.info["n_ops"], STEP):
+    before = ws_ref.copy()
+    ref.run_range(x, t, out_h, i, min(i + STEP, ref.info["n_ops"]))
+    _lib.check(L.sbm_debug_forward_range(eng.h, xd.data_ptr(), td.data_ptr(), out_d.data_ptr(), i, min(i + STEP, ref.info["n_ops"]), None))
+    _lib.check(L.sbm_debug_read_workspace(eng.h, 0, n_ws, host.ctypes.data))
+    changed = np.isfinite(ws_ref) & ~((ws_ref == before) & np.isfinite(before))
+    if not changed.any():
+        continue
+    want, got = ws_ref[changed], host[changed]
+    scale = max(np.abs(want).max(), 1e-6); err = np.abs(got - want)
+    bad = err > 3e-5 * scale
+    if bad.any():
+        idx = np.flatnonzero(changed)[bad]
+        print(f"ops [{i},{i+STEP}) {[ref.op_name(j) for j in range(i, min(i + STEP, ref.info[chr(110)+chr(95)+chr(111)+chr(112)+chr(115)]))]}: {bad.sum()}/{bad.size} bad, max err {err.max():.3e} scale {scale:.3e}; first bad ws offsets {idx[:6]} .. {idx[-3:]}", flush=True)
+        # resync the GPU workspace from the reference is not possible; stop at the first failure
+        sys.exit(1)
+print("all ops match")
