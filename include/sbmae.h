@@ -87,6 +87,8 @@ int sbm_model_set_aux(sbm_model* m, const float* aux_dev);
  * 1 = dwconv7, 2 = linattn, 3 = attn, 4 = gn_res, 5 = sinus, 6 = nchw_to_pbc, 7 = bilinear); sums per forward. */
 int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps,
                       double* ms_by_kind, int* launches_by_kind, int n_kinds);
+/* Dense-convention GEMM FLOP per forward executed by seg_gemm launches (out2[0]) and by chain_kernel launches (out2[1]). */
+int sbm_model_gemm_flops(const sbm_model* m, double* out2);
 
 /* SDE description == the reference's SDE objects (sde_helper2.py:329-473). kind: 0 VPSDE, 1 subVPSDE, 2 VESDE;
  * (b0,b1) = (beta_min,beta_max) or (sigma_min,sigma_max). */

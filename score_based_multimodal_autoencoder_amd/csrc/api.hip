@@ -155,7 +155,16 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
       if (!op.chain) continue;
       any_chain = true;
       cops[i].kind = op.kind;
-      if (op.kind == OP_GEMM) { cops[i].g = m->dp.hot[i]; cops[i].P = op.g.Hout * op.g.Wout; }
+      if (op.kind == OP_GEMM) {
+        const GemmOp& go = op.g;
+        cops[i].gm.g = m->dp.hot[i]; cops[i].gm.cold = cold[i]; cops[i].P = go.Hout * go.Wout;
+        unsigned mask = 0;
+        if (go.KH * go.KW <= 32 && go.w_pix_stride == 0)
+          for (int pp = 0; pp < cops[i].P; ++pp)
+            for (int ky = 0; ky < go.KH; ++ky) for (int kx = 0; kx < go.KW; ++kx)
+              if (go.a_bcast || tap_source_pixel(pp / go.Wout, pp % go.Wout, ky, kx, go.stride, go.pad, go.transposed, go.up, go.a.H, go.a.W) >= 0) mask |= 1u << (ky * go.KW + kx);
+        cops[i].gm.tapmask = mask; cops[i].gm.tap_floats = go.Npad * go.Kp; cops[i].gm.w2_floats = go.has2 ? go.Npad * go.Kp2 : 0; cops[i].gm.ndesc = 0;
+      }
       else if (op.kind == OP_DWCONV7) cops[i].d = make_dw_args(op.dw, m->d_params, m->d_ws);
       else if (op.kind == OP_LINATTN || op.kind == OP_ATTN) cops[i].a = make_attn_args(op.at, m->d_ws);
       else if (op.kind == OP_GN_RES) cops[i].r = make_gnres_args(op.gr, m->d_params, m->d_ws);
@@ -296,14 +305,15 @@ int sbm_debug_chain_sync(sbm_model* m, unsigned* out, int n_words) {
 int sbm_debug_chain_stamps(sbm_model* m, int first, int count, unsigned long long* out_host) {
   if (!m || !out_host || count <= 0 || count > 256) return fail("sbm_debug_chain_stamps: bad arguments");
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 520));
-  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 520));
+  if (count > CHAIN_MAX_OPS) return fail("sbm_debug_chain_stamps: too many ops for one launch");
+  HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 1024));
+  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 1024));
   g_chain_dbg = d;
   const char* e = launch_chain(m->dp, first, count, m->own);
   g_chain_dbg = nullptr;
   if (e) { (void)hipFree(d); return fail(e); }
   HIPCHK(hipStreamSynchronize(m->own));
-  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (1 + 2 * count), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (1 + 10 * count), hipMemcpyDeviceToHost));   // + 8 trace slots per op
   (void)hipFree(d);
   return 0;
 }
@@ -333,6 +343,8 @@ int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev,
   return 0;
 }
 
+// Launches are issued exactly as run_plan issues them (a run of chain ops = ONE chain_kernel launch) and each carries its
+// own event pair; bucket k < 11 = op kind k launched as its own kernel, bucket 11 = chain_kernel.
 int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, double* ms_by_kind, int* launches_by_kind, int n_kinds) {
   if (!m || !in_dev || !out_dev || reps <= 0 || !ms_by_kind || !launches_by_kind) return fail("sbm_model_profile: bad arguments");
   for (int k = 0; k < n_kinds; ++k) { ms_by_kind[k] = 0; launches_by_kind[k] = 0; }
@@ -340,25 +352,48 @@ int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, flo
   const char* e = run_plan(m->dp, in_dev, t_dev, out_dev, st);       // warm-up
   if (e) return fail(e);
   HIPCHK(hipStreamSynchronize(st));
-  const size_t nops = m->plan.ops.size();
-  std::vector<hipEvent_t> ev(2 * nops);
+  const int nops = (int)m->plan.ops.size();
+  std::vector<hipEvent_t> ev(2 * (size_t)nops);
   for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+  std::vector<int> bucket;
   for (int r = 0; r < reps; ++r) {
     if (m->plan.time_off >= 0 && t_dev) HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, t_dev, sizeof(float) * m->plan.B, hipMemcpyDeviceToDevice, st));
-    for (size_t i = 0; i < nops; ++i) {
-      arm_profile_events(ev[2 * i], ev[2 * i + 1]);            // events ride on the kernel's own dispatch: begin -> end of the kernel
-      e = launch_op(m->dp, (int)i, in_dev, out_dev, st);
+    bucket.clear();
+    for (int i = 0; i < nops;) {
+      int n = 1;
+      const size_t l = bucket.size();
+      arm_profile_events(ev[2 * l], ev[2 * l + 1]);            // events ride on the kernel's own dispatch: begin -> end of the kernel
+      if (m->plan.ops[i].chain) {
+        while (i + n < nops && m->plan.ops[i + n].chain) ++n;
+        if (n > CHAIN_MAX_OPS) n = CHAIN_MAX_OPS;              // one launch per event pair
+        e = launch_chain(m->dp, i, n, st);
+        bucket.push_back(11);
+      } else {
+        e = launch_op(m->dp, i, in_dev, out_dev, st);
+        bucket.push_back(m->plan.ops[i].kind);
+      }
       arm_profile_events(nullptr, nullptr);
       if (e) return fail(e);
+      i += n;
     }
     HIPCHK(hipStreamSynchronize(st));
-    for (size_t i = 0; i < nops; ++i) {
-      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
-      const int k = m->plan.ops[i].kind;
+    for (size_t l = 0; l < bucket.size(); ++l) {
+      float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[2 * l], ev[2 * l + 1]));
+      const int k = bucket[l];
       if (k < n_kinds) { ms_by_kind[k] += ms / reps; if (r == 0) launches_by_kind[k] += 1; }
     }
   }
   for (auto& x : ev) (void)hipEventDestroy(x);
+  return 0;
+}
+
+// Dense-convention GEMM FLOP (2*MAC, zero-padding taps counted) per forward, split by the kernel that executes them:
+// out[0] = seg_gemm launches, out[1] = chain_kernel launches.
+int sbm_model_gemm_flops(const sbm_model* m, double* out2) {
+  if (!m || !out2) return fail("sbm_model_gemm_flops: bad arguments");
+  double chain = 0.0;
+  for (const Op& op : m->plan.ops) if (op.kind == OP_GEMM && op.chain) chain += op.flops_dense;
+  out2[0] = m->plan.flops_dense_gemm - chain; out2[1] = chain;
   return 0;
 }
 

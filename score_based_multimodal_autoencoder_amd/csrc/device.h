@@ -41,7 +41,18 @@ AttnArgs make_attn_args(const AttnOp& o, float* ws);
 GnResArgs make_gnres_args(const GnResOp& o, const float* prm, float* ws);
 
 // ---- XCD-resident chain kernel (chain.hip): a run of low-resolution ops executed by ONE launch ----
-struct ChainOp { int kind; int P; int pad0, pad1; GemmHot g; DwArgs d; AttnArgs a; GnResArgs r; };
+struct ChainGemm {
+  GemmHot g; GemmCold cold;
+  unsigned tapmask;          // weight taps source 1 actually reads (zero-padding taps never are): prefetch hint
+  int tap_floats;            // floats per tap block = Npad * Kp
+  int w2_floats;             // floats of the source-2 weight block (0 if none)
+  int ndesc;                 // chunk descriptors over all pixels
+};
+struct ChainOp {
+  int kind; int P; int pad0, pad1;
+  union { ChainGemm gm; DwArgs d; AttnArgs a; GnResArgs r; };
+};
+constexpr int CHAIN_MAX_OPS = 64;   // ops per launch (their descriptors are staged in LDS)
 struct ChainSync {
   unsigned count[8];        // workgroups registered per XCD
   unsigned arrived;         // total registered

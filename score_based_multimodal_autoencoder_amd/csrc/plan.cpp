@@ -394,6 +394,7 @@ class Builder {
     double dense_taps = s.transposed ? (double)s.a.H * s.a.W * s.kh * s.kw : (double)P * s.kh * s.kw;
     plan->flops_dense += 2.0 * B * s.cout * (dense_taps * s.cin_true + (s.has2 ? (double)P * s.cin2 : 0.0));
     plan->flops_dense_gemm += 2.0 * B * s.cout * (dense_taps * s.cin_true + (s.has2 ? (double)P * s.cin2 : 0.0));
+    op.flops_dense = 2.0 * B * s.cout * (dense_taps * s.cin_true + (s.has2 ? (double)P * s.cin2 : 0.0));
     op.flops = 2.0 * B * g.Npad * (taps_valid * s.a.C + (s.has2 ? (double)P * s.a2.C : 0.0));
     plan->flops_exec += op.flops;
     return res;
@@ -505,8 +506,8 @@ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 int chain_pix_from_env() {
   const char* e = std::getenv("SBM_CHAIN_PIX");
-  const int v = e ? std::atoi(e) : 4;
-  return v < 0 ? 0 : (v > 16 ? 16 : v);
+  const int v = e ? std::atoi(e) : 16;
+  return v < 0 ? 0 : (v > 64 ? 64 : v);
 }
 
 bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Plan* plan) {

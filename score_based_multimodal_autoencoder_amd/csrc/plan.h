@@ -135,6 +135,7 @@ struct Op {
   int kind = 0;
   std::string name;       // reference layer this op implements (for profiles and error messages)
   double flops = 0;       // 2*MAC this op issues (padding taps skipped, channel padding included)
+  double flops_dense = 0; // GEMM ops: 2*MAC in the dense convention (zero-padding taps counted), the roofline numerator
   int chain = 0;          // 1: runs inside the XCD-resident chain kernel (low-resolution ops; GEMM tile 32x32) -- chain.hip
   GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf; Gn32Op gn; AttnQkvOp aq;
 };
@@ -164,7 +165,7 @@ struct Plan {
 };
 
 // Ops whose pixel grid has at most this many pixels run inside the XCD-resident chain kernel (0 = none).  Read from the
-// environment variable SBM_CHAIN_PIX by the Unet plan builder (default 4: the 2x2 and 1x1 levels).
+// environment variable SBM_CHAIN_PIX by the Unet plan builder (default 16: the 4x4, 2x2 and 1x1 levels).
 int chain_pix_from_env();
 
 struct UnetCfg {

@@ -16,7 +16,7 @@ names = []
 for i in range(n):
     L.sbm_debug_op_name(eng.h, i, buf, 256); names.append(buf.value.decode())
 # find the chain run: ask the library by trying ranges (ops marked chain are those the stamps call accepts)
-st = (ctypes.c_uint64 * 520)()
+st = (ctypes.c_uint64 * 1024)()
 runs = []; cur = None
 for i in range(n):
     if L.sbm_debug_chain_stamps(eng.h, i, 1, st) == 0:
@@ -29,12 +29,16 @@ first, count = max(runs, key=lambda r: r[1])
 print("chain run: ops", first, "..", first + count - 1)
 for rep in range(2):
     _lib.check(L.sbm_debug_chain_stamps(eng.h, first, count, st))
-v = list(st)[:1 + 2 * count]
-tot = (v[-1] - v[0]) / 2400.0
+v = list(st)[:1 + 10 * count]
+tot = (v[2 * count] - v[0]) / 2400.0
 print(f"{'op':46s} {'work us':>8} {'wait us':>8}")
 prev = v[0]
 for k in range(count):
     w = (v[1 + 2 * k] - prev) / 2400.0; b = (v[2 + 2 * k] - v[1 + 2 * k]) / 2400.0
-    print(f"{names[first + k][:46]:46s} {w:8.2f} {b:8.2f}")
+    tr = v[1 + 2 * count + 8 * k: 1 + 2 * count + 8 * k + 5]
+    extra = ""
+    if tr[0]:
+        extra = "  | setup+GN %.2f  tables+epi-loads %.2f  K-loop %.2f  reduce+epilogue %.2f" % tuple((tr[i + 1] - tr[i]) / 2400.0 if tr[i + 1] and tr[i] else 0 for i in range(4))
+    print(f"{names[first + k][:46]:46s} {w:8.2f} {b:8.2f}{extra}")
     prev = v[2 + 2 * k]
 print(f"total {tot:.1f} us for {count} ops")
