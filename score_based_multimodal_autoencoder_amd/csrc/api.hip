@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
@@ -27,6 +28,7 @@ struct sbm_model {
   GemmCold* d_cold = nullptr;    // one per op (only the GEMM entries are meaningful)
   ChainOp* d_chain_ops = nullptr; // one per op (filled for ops marked op.chain)
   ChainSync* d_chain_sync = nullptr;
+  int* d_chain_sched = nullptr;   // unit schedules of the chain GEMMs
   const float* aux_persistent = nullptr;   // z_cond used by sbm_sampler_run (sbm_model_set_aux)
   DevPlan dp;
   // sampler scratch (score nets only)
@@ -99,6 +101,7 @@ void sbm_model_destroy(sbm_model* m) {
   if (m->d_cold) (void)hipFree(m->d_cold);
   if (m->d_chain_ops) (void)hipFree(m->d_chain_ops);
   if (m->d_chain_sync) (void)hipFree(m->d_chain_sync);
+  if (m->d_chain_sched) (void)hipFree(m->d_chain_sched);
   if (m->d_score) (void)hipFree(m->d_score);
   if (m->d_norms) (void)hipFree(m->d_norms);
   if (m->d_counter) (void)hipFree(m->d_counter);
@@ -149,6 +152,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
     // op table of the XCD-resident chain kernel (chain.hip)
     bool any_chain = false;
     std::vector<ChainOp> cops(nops);
+    std::vector<int> sched_all; std::vector<size_t> sched_at(nops, (size_t)-1);
     for (size_t i = 0; i < nops; ++i) {
       const Op& op = m->plan.ops[i];
       std::memset(&cops[i], 0, sizeof(ChainOp));
@@ -163,7 +167,24 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
           for (int pp = 0; pp < cops[i].P; ++pp)
             for (int ky = 0; ky < go.KH; ++ky) for (int kx = 0; kx < go.KW; ++kx)
               if (go.a_bcast || tap_source_pixel(pp / go.Wout, pp % go.Wout, ky, kx, go.stride, go.pad, go.transposed, go.up, go.a.H, go.a.W) >= 0) mask |= 1u << (ky * go.KW + kx);
-        cops[i].gm.tapmask = mask; cops[i].gm.tap_floats = go.Npad * go.Kp; cops[i].gm.w2_floats = go.has2 ? go.Npad * go.Kp2 : 0; cops[i].gm.ndesc = 0;
+        cops[i].gm.tapmask = mask; cops[i].gm.tap_floats = go.Npad * go.Kp; cops[i].gm.w2_floats = go.has2 ? go.Npad * go.Kp2 : 0;
+        // unit schedule: longest-processing-time over 32 workgroups, cost = K chunks of the unit's pixel
+        const int P = cops[i].P, nblk = ((go.out_nchw ? go.N : go.out.C) + 31) / 32, units = P * nblk;
+        std::vector<int> cost(P, 0);
+        for (int pp = 0; pp < P; ++pp) {
+          int taps = 0;
+          for (int ky = 0; ky < go.KH; ++ky) for (int kx = 0; kx < go.KW; ++kx)
+            if (go.a_bcast || tap_source_pixel(pp / go.Wout, pp % go.Wout, ky, kx, go.stride, go.pad, go.transposed, go.up, go.a.H, go.a.W) >= 0) ++taps;
+          cost[pp] = taps * (go.Kp / 32) + (go.has2 ? go.Kp2 / 32 : 0);
+        }
+        std::vector<int> order(units);
+        for (int u = 0; u < units; ++u) order[u] = u;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a / nblk] > cost[b / nblk]; });
+        std::vector<std::vector<int>> bins(32); std::vector<long> load(32, 0);
+        for (int u : order) { int best = 0; for (int k = 1; k < 32; ++k) if (load[k] < load[best]) best = k; bins[best].push_back(u); load[best] += cost[u / nblk]; }
+        size_t rounds = 0; for (auto& b : bins) rounds = std::max(rounds, b.size());
+        sched_at[i] = sched_all.size(); cops[i].gm.rounds = (int)rounds;
+        for (size_t r = 0; r < rounds; ++r) for (int k = 0; k < 32; ++k) sched_all.push_back(r < bins[k].size() ? bins[k][r] : -1);
       }
       else if (op.kind == OP_DWCONV7) cops[i].d = make_dw_args(op.dw, m->d_params, m->d_ws);
       else if (op.kind == OP_LINATTN || op.kind == OP_ATTN) cops[i].a = make_attn_args(op.at, m->d_ws);
@@ -173,8 +194,11 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
     if (any_chain) {
       if ((e = hipMalloc(&m->d_chain_ops, sizeof(ChainOp) * nops)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(chain ops)", e); }
       if ((e = hipMalloc(&m->d_chain_sync, sizeof(ChainSync))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(chain sync)", e); }
-      if ((e = hipMemcpy(m->d_chain_ops, cops.data(), sizeof(ChainOp) * nops, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(chain ops)", e); }
       if ((e = hipMemset(m->d_chain_sync, 0, sizeof(ChainSync))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemset(chain sync)", e); }
+      if ((e = hipMalloc(&m->d_chain_sched, sizeof(int) * (sched_all.size() + 1))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(chain schedule)", e); }
+      if ((e = hipMemcpy(m->d_chain_sched, sched_all.data(), sizeof(int) * sched_all.size(), hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(chain schedule)", e); }
+      for (size_t i = 0; i < nops; ++i) if (sched_at[i] != (size_t)-1) cops[i].gm.sched = m->d_chain_sched + sched_at[i];
+      if ((e = hipMemcpy(m->d_chain_ops, cops.data(), sizeof(ChainOp) * nops, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(chain ops)", e); }
       int dev = 0, cus = 0;
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -40,10 +40,24 @@ DEVINL float chain_act(int act, float v) {
 
 DEVINL unsigned xcc_id() { unsigned v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 7u; }
 
+// Pointers reach the kernel through descriptor structs, i.e. as generic pointers: loads through them would be FLAT
+// instructions, which count on vmcnt AND lgkmcnt and force the compiler to drain everything (`s_waitcnt vmcnt(0)
+// lgkmcnt(0)`) before each use -- no prefetch would ever overlap.  Casting to the global address space gives
+// global_load (vmcnt only, returned in order), so the waits become counted.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) f32x4n gfloat4;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) i32x4 const_i32x4;
+DEVINL float4 ldw4(const float* p) { const f32x4n v = *(const gfloat4*)(unsigned long long)p; return make_float4(v.x, v.y, v.z, v.w); }   // cached global load (weights, tables)
+DEVINL void st4(float* p, float4 v) { f32x4n t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *(gfloat4*)(unsigned long long)p = t; }
+DEVINL int4 sload16(const int4* p) { const i32x4 v = *(const_i32x4*)(unsigned long long)p; return make_int4(v.x, v.y, v.z, v.w); }   // uniform: s_load_dwordx4
+
 // L1-bypassing loads (global_load ... sc1): data another CU of this XCD stored earlier in the same launch
-DEVINL float ld1(const float* p) { return __hip_atomic_load(const_cast<float*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVINL float ld1(const float* p) { return __hip_atomic_load((gfloat*)(unsigned long long)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEVINL float2 ld2(const float* p) {
-  const unsigned long long v = __hip_atomic_load(reinterpret_cast<unsigned long long*>(const_cast<float*>(p)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long v = __hip_atomic_load((gu64*)(unsigned long long)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 DEVINL float4 ld4(const float* p) { const float2 a = ld2(p), b = ld2(p + 2); return make_float4(a.x, a.y, b.x, b.y); }
@@ -158,7 +172,7 @@ DEVINL void load_frag(Frag& f, const GemmHot& g, const int4 d, int b0, int B, in
 #pragma unroll
   for (int i = 0; i < 8; ++i) f.araw[i] = ld2(ap + (long long)min(b0 + (lane >> 4) + 4 * i, B - 1) * lda);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { const float4 v = *reinterpret_cast<const float4*>(wp + 4 * j); f.w[4 * j] = v.x; f.w[4 * j + 1] = v.y; f.w[4 * j + 2] = v.z; f.w[4 * j + 3] = v.w; }
+  for (int j = 0; j < 4; ++j) { const float4 v = ldw4(wp + 4 * j); f.w[4 * j] = v.x; f.w[4 * j + 1] = v.y; f.w[4 * j + 2] = v.z; f.w[4 * j + 3] = v.w; }
 }
 
 // araw -> this wave's LDS tile -> a[16] = A[row fi][16 fh + j]
@@ -205,9 +219,15 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
   float* atile = c.smem + c.wave * 32 * A_LD;
   const int units = P * nblk;
   const int row = (c.tid >> 3) & 31, c4 = (c.tid & 7) * 4;       // epilogue: threads 0..255 own 4 columns of one row
-  for (int u = c.slot; u < units; u += c.cs) {
+  const int* __restrict__ sched = uniform_ptr(m.sched);
+  const int rounds = __builtin_amdgcn_readfirstlane(m.rounds);
+  const bool use_sched = sched != nullptr && c.cs == 32;        // the schedule was built for 32 workgroups per cluster
+  const int trips = use_sched ? rounds : (units - c.slot + c.cs - 1) / c.cs;
+  for (int it = 0; it < trips; ++it) {
+    const int u = use_sched ? sched[it * 32 + c.slot] : c.slot + it * c.cs;
+    if (u < 0 || u >= units) continue;
     const int p = u / nblk, nb = u - p * nblk, n0 = nb * 32;
-    const int4 hd = g.hdr[p];
+    const int4 hd = sload16(g.hdr + p);
     const int4* __restrict__ dsc = g.desc + hd.x;
     const int total = hd.y, n1 = gn ? hd.z : 0;
     const int brow = min(n0 + fi, g.Npad - 1);
@@ -216,10 +236,10 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
     const bool ok = c.tid < 256 && n < cold.nstore && bb < c.B;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gs = bv, gb = bv, rv = bv;
     if (ok) {
-      if (cold.bias) bv = *reinterpret_cast<const float4*>(cold.bias + (long long)p * cold.bias_pix_stride + n);
+      if (cold.bias) bv = ldw4(cold.bias + (long long)p * cold.bias_pix_stride + n);
       if (gn) {
-        gs = *reinterpret_cast<const float4*>(cold.gn_s + (long long)p * g.Npad + n);
-        gb = *reinterpret_cast<const float4*>(cold.gn_b1 + (long long)p * g.Npad + n);
+        gs = ldw4(cold.gn_s + (long long)p * g.Npad + n);
+        gb = ldw4(cold.gn_b1 + (long long)p * g.Npad + n);
       }
       if (cold.R) rv = ld4(cold.R + ((long long)hd.w * c.B + bb) * cold.ldr + n);
     }
@@ -227,14 +247,14 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // this wave's chunks of [lo, hi): lo + wave, lo + wave + NW, ...; PF of them in flight
-    constexpr int PF = 4;
+    constexpr int PF = 2;
     auto run = [&](int lo, int hi) {
       const int first = lo + c.wave;
       if (first >= hi) return;
       const int nk = (hi - first + NW - 1) / NW;
       Frag f[PF];
 #pragma unroll
-      for (int sI = 0; sI < PF; ++sI) if (sI < nk) load_frag(f[sI], g, dsc[first + sI * NW], c.b0, c.B, c.lane, brow, fh);
+      for (int sI = 0; sI < PF; ++sI) if (sI < nk) load_frag(f[sI], g, sload16(dsc + first + sI * NW), c.b0, c.B, c.lane, brow, fh);
       for (int k = 0; k < nk; k += PF) {
 #pragma unroll
         for (int sI = 0; sI < PF; ++sI) {
@@ -243,7 +263,7 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
             stage_frag(f[sI], atile, c.lane, av);
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], f[sI].w[j], acc, 0, 0, 0);
-            if (k + sI + PF < nk) load_frag(f[sI], g, dsc[first + (k + sI + PF) * NW], c.b0, c.B, c.lane, brow, fh);
+            if (k + sI + PF < nk) load_frag(f[sI], g, sload16(dsc + first + (k + sI + PF) * NW), c.b0, c.B, c.lane, brow, fh);
           }
         }
       }
@@ -281,7 +301,7 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
       v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = chain_act(cold.act, v[e]);
-      *reinterpret_cast<float4*>(g.out + ((long long)p * c.B + bb) * cold.ldo + n) = make_float4(v[0], v[1], v[2], v[3]);
+      st4(g.out + ((long long)p * c.B + bb) * cold.ldo + n, make_float4(v[0], v[1], v[2], v[3]));
       s = (v[0] + v[1]) + (v[2] + v[3]); q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
     if (cold.stat_out && c.tid < 256) {
@@ -312,13 +332,29 @@ DEVINL void chain_dw(const DwArgs& dsrc, Ctx& c) {
       for (int c4 = cl; c4 * 4 < d.C; c4 += lanes) {
         const int ch = c4 * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int ky = ky0; ky < ky1; ++ky)
-          for (int kx = kx0; kx < kx1; ++kx) {
-            const int qp = (oy - 3 + ky) * d.W + (ox - 3 + kx);
-            const float4 x = ld4(d.in + ((long long)qp * d.B + b) * d.ldi + ch);
-            const float4 w = *reinterpret_cast<const float4*>(d.w + (ky * 7 + kx) * d.C + ch);
-            acc.x = fmaf(x.x, w.x, acc.x); acc.y = fmaf(x.y, w.y, acc.y); acc.z = fmaf(x.z, w.z, acc.z); acc.w = fmaf(x.w, w.w, acc.w);
+        if (d.H <= 4 && d.W <= 4) {
+          // the window covers the whole image: walk the source pixels in raster order (= the tap order), four loads in flight
+          for (int q0 = 0; q0 < P; q0 += 4) {
+            float4 x[4], w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int qp = min(q0 + j, P - 1), qy = qp / d.W, qx = qp - qy * d.W;
+              x[j] = ld4(d.in + ((long long)qp * d.B + b) * d.ldi + ch);
+              w[j] = *reinterpret_cast<const float4*>(d.w + ((qy - oy + 3) * 7 + (qx - ox + 3)) * d.C + ch);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (q0 + j < P) { acc.x = fmaf(x[j].x, w[j].x, acc.x); acc.y = fmaf(x[j].y, w[j].y, acc.y); acc.z = fmaf(x[j].z, w[j].z, acc.z); acc.w = fmaf(x[j].w, w[j].w, acc.w); }
           }
+        } else {
+          for (int ky = ky0; ky < ky1; ++ky)
+            for (int kx = kx0; kx < kx1; ++kx) {
+              const int qp = (oy - 3 + ky) * d.W + (ox - 3 + kx);
+              const float4 x = ld4(d.in + ((long long)qp * d.B + b) * d.ldi + ch);
+              const float4 w = *reinterpret_cast<const float4*>(d.w + (ky * 7 + kx) * d.C + ch);
+              acc.x = fmaf(x.x, w.x, acc.x); acc.y = fmaf(x.y, w.y, acc.y); acc.z = fmaf(x.z, w.z, acc.z); acc.w = fmaf(x.w, w.w, acc.w);
+            }
+        }
         const float4 bi = *reinterpret_cast<const float4*>(d.bias + ch);
         acc.x += bi.x; acc.y += bi.y; acc.z += bi.z; acc.w += bi.w;
         if (d.cond) {
@@ -344,8 +380,89 @@ DEVINL void chain_dw(const DwArgs& dsrc, Ctx& c) {
 }
 
 // LinearAttention core, one wave per (sample, head); see linattn_kernel
+// n <= 16: every global load of a task (k for all pixels, this half's q, the v tile) is issued before the first use; the
+// arithmetic and its order are those of linattn_kernel.
+DEVINL void chain_linattn16(const AttnArgs a, Ctx& c) {
+  float* my = c.smem + c.wave * 1120;
+  float (*ctx)[33] = reinterpret_cast<float (*)[33]>(my);      // overlays the v tile: v is dead once ctx is formed
+  float* sv = my;                                              // [pixel][32]
+  float (*qs)[32] = reinterpret_cast<float (*)[32]>(my + 32 * 33);
+  const int d = c.lane & 31, half = c.lane >> 5;
+  const int ntask = 32 * a.heads, hd = a.heads * 32;
+  const long long pstride = (long long)a.B * a.ldq;
+  for (int base = 0; base < ntask; base += c.cs * NW) {
+    const int t = base + c.slot * NW + c.wave;
+    const int bi = c.b0 + t / a.heads, h = t % a.heads;
+    const bool active = t < ntask && bi < c.B;
+    const int b = min(bi, c.B - 1);
+    const float* qb = a.qkv + (long long)b * a.ldq + h * 32;
+    float kk[16], qq[8];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kk[i] = ld1(qb + (long long)min(i, a.n - 1) * pstride + hd + d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qq[j] = ld1(qb + (long long)min(half + 2 * j, a.n - 1) * pstride + d);
+    float2 vv[4];                                              // v tile: n x 32 floats, 16 lanes per pixel row
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vv[j] = ld2(qb + (long long)min((c.lane >> 4) + 4 * j, a.n - 1) * pstride + 2 * hd + (c.lane & 15) * 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(sv + ((c.lane >> 4) + 4 * j) * 32 + (c.lane & 15) * 2) = vv[j];
+    float kmax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if ((i & 1) == half && i < a.n) kmax = fmaxf(kmax, kk[i]);
+    kmax = fmaxf(kmax, __shfl_xor(kmax, 32));
+    float ksum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) if ((i & 1) == half && i < a.n) ksum += expf(kk[i] - kmax);
+    ksum += __shfl_xor(ksum, 32);
+    const float kinv = 1.0f / ksum;
+    float cc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cc[e] = 0.f;
+    __syncthreads();                                           // v tile written
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (i < a.n) {
+        const float kv = expf(kk[i] - kmax) * kinv;
+        const float* vrow = sv + i * 32 + half * 16;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) cc[e] = fmaf(kv, vrow[e], cc[e]);
+      }
+    }
+    __syncthreads();                                           // everyone is done reading v: ctx may overlay it
+#pragma unroll
+    for (int e = 0; e < 16; ++e) ctx[d][half * 16 + e] = cc[e];
+    __syncthreads();
+    float col[32];
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) col[dd] = ctx[dd][d];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = 2 * j + half;
+      if (2 * j < a.n) {                                       // uniform
+        const bool ok = i < a.n;
+        const float qv = ok ? qq[j] : 0.f;
+        float m = qv;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        const float e = expf(qv - m);
+        float s = e;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        qs[half][d] = e / s * a.scale;
+        __syncthreads();
+        float o = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 32; ++dd) o = fmaf(col[dd], qs[half][dd], o);
+        if (ok && active) a.out[((long long)i * a.B + b) * a.ldo + h * 32 + d] = o;
+        __syncthreads();
+      }
+    }
+  }
+}
+
 DEVINL void chain_linattn(const AttnArgs& asrc, Ctx& c) {
   const AttnArgs a = uniform_copy(asrc);
+  if (a.n <= 16) { chain_linattn16(a, c); return; }
   float* my = c.smem + c.wave * 1120;
   float (*ctx)[33] = reinterpret_cast<float (*)[33]>(my);
   float (*qs)[32] = reinterpret_cast<float (*)[32]>(my + 32 * 33);

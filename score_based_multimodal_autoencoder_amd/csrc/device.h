@@ -46,13 +46,14 @@ struct ChainGemm {
   unsigned tapmask;          // weight taps source 1 actually reads (zero-padding taps never are): prefetch hint
   int tap_floats;            // floats per tap block = Npad * Kp
   int w2_floats;             // floats of the source-2 weight block (0 if none)
-  int ndesc;                 // chunk descriptors over all pixels
+  int rounds;                // unit schedule for a 32-workgroup cluster: sched[r * 32 + slot] = unit or -1, r < rounds
+  const int* sched;          // (longest-processing-time assignment by chunk count; null -> plain striding)
 };
 struct ChainOp {
   int kind; int P; int pad0, pad1;
   union { ChainGemm gm; DwArgs d; AttnArgs a; GnResArgs r; };
 };
-constexpr int CHAIN_MAX_OPS = 64;   // ops per launch (their descriptors are staged in LDS)
+constexpr int CHAIN_MAX_OPS = 96;   // ops per launch (their descriptors are staged in LDS)
 struct ChainSync {
   unsigned count[8];        // workgroups registered per XCD
   unsigned arrived;         // total registered

@@ -465,13 +465,20 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const DwArgs d) {
     for (int c4 = cl; c4 * 4 < d.C; c4 += d.lanes) {
       const int c = c4 * 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int ky = ky0; ky < ky1; ++ky)
-        for (int kx = kx0; kx < kx1; ++kx) {
-          const int qp = (oy - 3 + ky) * d.W + (ox - 3 + kx);
-          const float4 x = *reinterpret_cast<const float4*>(d.in + ((long long)qp * d.B + b) * d.ldi + c);
-          const float4 w = *reinterpret_cast<const float4*>(d.w + (ky * 7 + kx) * d.C + c);
-          acc.x = fmaf(x.x, w.x, acc.x); acc.y = fmaf(x.y, w.y, acc.y); acc.z = fmaf(x.z, w.z, acc.z); acc.w = fmaf(x.w, w.w, acc.w);
+      for (int ky = ky0; ky < ky1; ++ky) {
+        // the 7 taps of a row as one batch of independent loads (out-of-image taps: clamped address, zero weight)
+        float4 x[7], w[7];
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const bool in = kx >= kx0 && kx < kx1;
+          const int qp = (oy - 3 + ky) * d.W + min(max(ox - 3 + kx, 0), d.W - 1);
+          x[kx] = *reinterpret_cast<const float4*>(d.in + ((long long)qp * d.B + b) * d.ldi + c);
+          w[kx] = in ? *reinterpret_cast<const float4*>(d.w + (ky * 7 + kx) * d.C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx)
+          if (kx >= kx0 && kx < kx1) { acc.x = fmaf(x[kx].x, w[kx].x, acc.x); acc.y = fmaf(x[kx].y, w[kx].y, acc.y); acc.z = fmaf(x[kx].z, w[kx].z, acc.z); acc.w = fmaf(x[kx].w, w[kx].w, acc.w); }
+      }
       const float4 bi = *reinterpret_cast<const float4*>(d.bias + c);
       acc.x += bi.x; acc.y += bi.y; acc.z += bi.z; acc.w += bi.w;
       if (d.cond) {
@@ -537,6 +544,68 @@ __global__ __launch_bounds__(64) void linattn_kernel(const AttnArgs a) {
     const int i = i0 + half;
     const bool ok = i < a.n;
     const float qv = ok ? base[i * pstride + d] : 0.f;
+    float m = qv;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float e = expf(qv - m);
+    float s = e;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    qs[half][d] = e / s * a.scale;
+    __syncthreads();
+    float o = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) o = fmaf(col[dd], qs[half][dd], o);
+    if (ok) a.out[((long long)i * a.B + b) * a.ldo + h * 32 + d] = o;
+    __syncthreads();
+  }
+}
+
+// Same arithmetic, in the same order, with q/k/v of the (sample, head) staged through LDS by coalesced float4 loads (one
+// latency instead of a dependent load per pixel and pass).  n <= 64.
+__global__ __launch_bounds__(64) void linattn_lds_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sq[64 * 32], sk[64 * 32], sv[64 * 32];      // [pixel][d]
+  __shared__ float ctx[32][33];
+  __shared__ float qs[2][32];
+  const int lane = threadIdx.x, d = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+  const int hd = a.heads * 32;
+  const float* base = a.qkv + (long long)b * a.ldq + h * 32;
+  const long long pstride = (long long)a.B * a.ldq;
+  for (int idx = lane; idx < a.n * 8; idx += 64) {
+    const int i = idx >> 3, c4 = (idx & 7) * 4;
+    const float* r = base + i * pstride + c4;
+    reinterpret_cast<float4*>(sq)[idx] = *reinterpret_cast<const float4*>(r);
+    reinterpret_cast<float4*>(sk)[idx] = *reinterpret_cast<const float4*>(r + hd);
+    reinterpret_cast<float4*>(sv)[idx] = *reinterpret_cast<const float4*>(r + 2 * hd);
+  }
+  __syncthreads();
+  float kmax = -INFINITY;
+  for (int i = half; i < a.n; i += 2) kmax = fmaxf(kmax, sk[i * 32 + d]);
+  kmax = fmaxf(kmax, __shfl_xor(kmax, 32));
+  float ksum = 0.f;
+  for (int i = half; i < a.n; i += 2) ksum += expf(sk[i * 32 + d] - kmax);
+  ksum += __shfl_xor(ksum, 32);
+  const float kinv = 1.0f / ksum;
+  float c[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c[e] = 0.f;
+  for (int i = 0; i < a.n; ++i) {
+    const float kv = expf(sk[i * 32 + d] - kmax) * kinv;
+    const float* vrow = sv + i * 32 + half * 16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = fmaf(kv, vrow[e], c[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) ctx[d][half * 16 + e] = c[e];
+  __syncthreads();
+  float col[32];
+#pragma unroll
+  for (int dd = 0; dd < 32; ++dd) col[dd] = ctx[dd][d];
+  for (int i0 = 0; i0 < a.n; i0 += 2) {
+    const int i = i0 + half;
+    const bool ok = i < a.n;
+    const float qv = ok ? sq[i * 32 + d] : 0.f;
     float m = qv;
 #pragma unroll
     for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
@@ -870,7 +939,8 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       const AttnOp& o = op.at; const AttnArgs a = make_attn_args(o, ws);
       if (o.dh != 32) return "attention: dim_head must be 32";
       if (op.kind == OP_ATTN && a.n > 64) return "softmax attention: more than 64 positions";
-      if (op.kind == OP_LINATTN) SBM_KLAUNCH(linattn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
+      if (op.kind == OP_LINATTN && a.n <= 64 && (a.ldq & 3) == 0) SBM_KLAUNCH(linattn_lds_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
+      else if (op.kind == OP_LINATTN) SBM_KLAUNCH(linattn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
       else SBM_KLAUNCH(attn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
     } break;
     case OP_GN_RES: {

@@ -253,9 +253,12 @@ class Builder {
   int chain_pix = 0;        // ops with P <= chain_pix are marked for the chain kernel
 
   // ---- tile choice ----
-  static void choose_tile(int B, int P, int nstore, int* BM, int* BN) {
+  // kchunks: K depth in 32-wide chunks; a very short K loop makes the launch prologue/epilogue-bound, where more, smaller
+  // workgroups overlap better than few large ones
+  static void choose_tile(int B, int P, int nstore, int* BM, int* BN, int kchunks = 1 << 20) {
     const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
     for (auto& c : cand) {
+      if (kchunks <= 4 && c[0] > 64) continue;
       if (c[1] > 64 && nstore <= 64) continue;
       if (c[0] > 64 && B <= 64) continue;
       long blocks = (long)P * ceil_div(B, c[0]) * ceil_div(nstore, c[1]);
@@ -366,7 +369,7 @@ class Builder {
     if (s.has_res) { g.has_res = 1; g.r = s.r; g.up2 = s.up2; }
     g.act = s.act;
     const int P = s.Hout * s.Wout;
-    choose_tile(B, P, nstore, &g.BM, &g.BN);
+    choose_tile(B, P, nstore, &g.BM, &g.BN, s.kh * s.kw * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0));
     if (chain_pix > 0 && P <= chain_pix && !s.out_nchw) { op.chain = 1; g.BM = 32; g.BN = 32; }
     ConvResult res;
     if (s.out_nchw) {
@@ -504,7 +507,12 @@ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace
 
-int chain_pix_from_env() {
+int chain_pix_from_env(int B) {
+  // The chain kernel gives each XCD (32 CUs) one 32-sample tile at a time: with fewer than ~6 tiles most of the chip idles
+  // and per-layer launches are faster.
+  const char* mb = std::getenv("SBM_CHAIN_MIN_B");
+  const int min_b = mb ? std::atoi(mb) : 192;
+  if (B < min_b) return 0;
   const char* e = std::getenv("SBM_CHAIN_PIX");
   const int v = e ? std::atoi(e) : 16;
   return v < 0 ? 0 : (v > 64 ? 64 : v);
@@ -514,7 +522,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
   try {
     std::vector<TensorSpec> specs = unet_tensor_specs(cfg);
     Builder b(plan, B, specs, tensors);
-    b.chain_pix = chain_pix_from_env();
+    b.chain_pix = chain_pix_from_env(B);
     UnetDims d = unet_dims(cfg);
     const int n = (int)d.in_out.size();
     const int Hp = next_pow2(cfg.H), Wp = next_pow2(cfg.W);       // unet_model.py:276-284

@@ -165,8 +165,9 @@ struct Plan {
 };
 
 // Ops whose pixel grid has at most this many pixels run inside the XCD-resident chain kernel (0 = none).  Read from the
-// environment variable SBM_CHAIN_PIX by the Unet plan builder (default 16: the 4x4, 2x2 and 1x1 levels).
-int chain_pix_from_env();
+// environment variable SBM_CHAIN_PIX by the Unet plan builder (default 16: the 4x4, 2x2 and 1x1 levels); batches smaller
+// than SBM_CHAIN_MIN_B (default 192) do not use the chain kernel.
+int chain_pix_from_env(int B);
 
 struct UnetCfg {
   int dim = 64, channels = 3, init_dim = 0, out_dim = 0;

@@ -1,8 +1,12 @@
-import os
 import sys
 
 import numpy as np
+import os
+
 import pytest
+
+# the XCD-resident chain kernel is used for batches >= 192 by default; the suites run it at every batch size
+os.environ.setdefault("SBM_CHAIN_MIN_B", "1")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

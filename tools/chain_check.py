@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Compare the chain-kernel forward (SBM_CHAIN_PIX=k) with the per-layer forward (SBM_CHAIN_PIX=0), per sample."""
 import os, sys
+os.environ.setdefault("SBM_CHAIN_MIN_B", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from score_based_multimodal_autoencoder_amd import _lib, synth

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Op-by-op: GPU (each op launched alone; chain ops through the chain kernel) vs the host plan interpreter."""
 import os, sys
+os.environ.setdefault("SBM_CHAIN_MIN_B", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch

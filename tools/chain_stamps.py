@@ -35,10 +35,13 @@ print(f"{'op':46s} {'work us':>8} {'wait us':>8}")
 prev = v[0]
 for k in range(count):
     w = (v[1 + 2 * k] - prev) / 2400.0; b = (v[2 + 2 * k] - v[1 + 2 * k]) / 2400.0
-    tr = v[1 + 2 * count + 8 * k: 1 + 2 * count + 8 * k + 5]
+    tr = v[1 + 2 * count + 8 * k: 1 + 2 * count + 8 * k + 8]
     extra = ""
     if tr[0]:
         extra = "  | setup+GN %.2f  tables+epi-loads %.2f  K-loop %.2f  reduce+epilogue %.2f" % tuple((tr[i + 1] - tr[i]) / 2400.0 if tr[i + 1] and tr[i] else 0 for i in range(4))
+    if tr[0] and tr[7] & 0xffff:
+        nchunk = tr[7] & 0xffff
+        extra += "  || wave0 last unit: %d chunks, per chunk: wait+stage %.0f cyc, mfma %.0f, refill-issue %.0f" % (nchunk, tr[5] / nchunk, tr[6] / nchunk, (tr[7] >> 16) / nchunk)
     print(f"{names[first + k][:46]:46s} {w:8.2f} {b:8.2f}{extra}")
     prev = v[2 + 2 * k]
 print(f"total {tot:.1f} us for {count} ops")
