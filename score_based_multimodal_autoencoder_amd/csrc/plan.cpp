@@ -462,6 +462,51 @@ BlockIO emit_convnext(Builder& b, const std::string& pre, const View& x, const C
 // x must carry GroupNorm partials (stat_off).  Result written to *dest (or a fresh tensor).
 View emit_attention(Builder& b, const std::string& pre, const View& x, int c, int64_t x_stat, int x_nparts, bool linear, View* dest) {
   const int H = x.H, W = x.W, P = H * W, hid = 128;
+  if (P == 1 && !std::getenv("SBM_NO_ATTN_FOLD")) {
+    // A single position: softmax over one element is 1, so both attention forms collapse to a linear map of v --
+    //   LinearAttention (unet_model.py:169-175): ctx[d][e] = v[e], out[e] = scale * v[e] * sum_d softmax_d(q)[d] = scale * v[e]
+    //   Attention       (unet_model.py:141-148): softmax over the single key = 1, out = v
+    // and to_qkv -> core -> to_out become ONE GEMM with W' = s * W_out * W_v (formed in double).  The only difference from the
+    // reference's arithmetic is that its sum of a softmax is 1 to within an ulp.
+    const float* wqkv = b.T(pre + "fn.fn.to_qkv.weight", (int64_t)3 * hid * c);
+    const std::string on = linear ? "fn.fn.to_out.0" : "fn.fn.to_out";
+    const float* wout = b.T(pre + on + ".weight", (int64_t)c * hid);
+    const double sc = linear ? 1.0 / std::sqrt(32.0) : 1.0;
+    std::vector<float> wf((size_t)c * c);
+    for (int o = 0; o < c; ++o)
+      for (int i = 0; i < c; ++i) {
+        double acc = 0.0;
+        for (int k = 0; k < hid; ++k) acc += (double)wout[(size_t)o * hid + k] * (double)wqkv[(size_t)(2 * hid + k) * c + i];
+        wf[(size_t)o * c + i] = (float)(sc * acc);
+      }
+    Builder::ConvSpec f;
+    f.name = pre + "fn.fn (to_qkv.v x to_out folded: one position)"; f.a = x; f.cm = ChanMap::identity(c); f.cin_true = c;
+    f.w = wf.data(); f.bias = b.T(pre + on + ".bias", c); f.cout = c; f.Hout = H; f.Wout = W;
+    f.gn = true; f.gn_part = x_stat; f.gn_nparts = x_nparts; f.gn_inv = 1.0f / ((float)c * P);
+    f.gamma = b.T(pre + "fn.norm.weight", c); f.beta = b.T(pre + "fn.norm.bias", c);
+    // executed 2*c*(3*hid) + attention + 2*hid*c per sample in the dense convention; account the reference's figure
+    const double dense_ref = 2.0 * b.B * ((double)c * 3 * hid + (double)hid * c) + 2.0 * b.B * 4 * (linear ? 2.0 * 32 * 32 : 2.0 * 32);
+    if (linear) {
+      f.want_stats = true;
+      Builder::ConvResult ro = b.emit_conv(f);
+      b.plan->ops.back().flops_dense = 2.0 * b.B * ((double)c * 3 * hid + (double)hid * c);
+      View out = dest ? *dest : b.new_act(H, W, c);
+      Op& op = b.push(OP_GN_RES, pre + "fn.fn.to_out.1+residual");
+      if (b.chain_pix > 0 && P <= b.chain_pix) op.chain = 1;
+      GnResOp& g = op.gr; g.B = b.B; g.u = ro.out; g.x = x; g.out = out;
+      g.part_off = ro.stat_off; g.nparts = ro.stat_nparts; g.inv_count = 1.0f / ((float)c * P);
+      g.gamma_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.weight", c), c, nullptr, x.C));
+      g.beta_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.bias", c), c, nullptr, x.C));
+      b.ws_free(ro.stat_off); b.free_act(ro.out);
+      b.plan->flops_dense += dense_ref - 2.0 * b.B * (double)c * c; b.plan->flops_dense_gemm += 2.0 * b.B * ((double)c * 3 * hid + (double)hid * c) - 2.0 * b.B * (double)c * c;
+      return out;
+    }
+    f.has_res = true; f.r = x; f.dest = dest;
+    View out = b.emit_conv(f).out;
+    b.plan->ops.back().flops_dense = 2.0 * b.B * ((double)c * 3 * hid + (double)hid * c);
+    b.plan->flops_dense += dense_ref - 2.0 * b.B * (double)c * c; b.plan->flops_dense_gemm += 2.0 * b.B * ((double)c * 3 * hid + (double)hid * c) - 2.0 * b.B * (double)c * c;
+    return out;
+  }
   Builder::ConvSpec q;
   q.name = pre + "fn.fn.to_qkv"; q.a = x; q.cm = ChanMap::identity(c); q.cin_true = c;
   q.w = b.T(pre + "fn.fn.to_qkv.weight", (int64_t)3 * hid * c); q.cout = 3 * hid; q.Hout = H; q.Wout = W;
