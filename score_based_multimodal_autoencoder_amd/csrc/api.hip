@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -177,6 +178,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
             if (go.a_bcast || tap_source_pixel(pp / go.Wout, pp % go.Wout, ky, kx, go.stride, go.pad, go.transposed, go.up, go.a.H, go.a.W) >= 0) ++taps;
           cost[pp] = taps * (go.Kp / 32) + (go.has2 ? go.Kp2 / 32 : 0);
         }
+        { int mx = 0; for (int pp = 0; pp < P; ++pp) mx = std::max(mx, cost[pp]); cops[i].gm.wpu = (mx <= 8 && units >= 128 && !std::getenv("SBM_NO_WPU")) ? 1 : 0; }   // pays only with >= 4 units per workgroup
         std::vector<int> order(units);
         for (int u = 0; u < units; ++u) order[u] = u;
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return cost[a / nblk] > cost[b / nblk]; });

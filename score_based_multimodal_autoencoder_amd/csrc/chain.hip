@@ -186,6 +186,99 @@ DEVINL void stage_frag(const Frag& f, float* tile, int lane, float* a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the tile may be overwritten by the next chunk
 }
 
+// Short-K GEMMs (1x1 convolutions, the 1x1 level): one unit per WAVE, the whole K walked by that wave -- no K split, no
+// cross-wave reduction, no workgroup barrier inside the unit loop, and up to 8 x 32 units in flight per cluster instead of 32.
+DEVINL void chain_gemm_wpu(const GemmHot& g, const GemmCold& cold, int P, bool gn, Ctx& c) {
+  const int fi = c.lane & 31, fh = c.lane >> 5;
+  const int nblk = (cold.nstore + 31) >> 5;
+  const int units = P * nblk;
+  float* tile = c.smem + c.wave * 32 * A_LD;                   // wave-private: A staging, then the output transpose
+  float rr[16];
+  if (gn) {
+#pragma unroll
+    for (int r2 = 0; r2 < 16; ++r2) rr[r2] = c.mr[(r2 & 3) + 8 * (r2 >> 2) + 4 * fh].y;
+  }
+  constexpr int PF = 2;
+  for (int u = c.slot * NW + c.wave; u < units; u += c.cs * NW) {
+    const int p = u / nblk, nb = u - p * nblk, n0 = nb * 32;
+    const int4 hd = sload16(g.hdr + p);
+    const int4* __restrict__ dsc = g.desc + hd.x;
+    const int total = hd.y, n1 = gn ? hd.z : 0;
+    const int brow = min(n0 + fi, g.Npad - 1);
+    // epilogue operands: lane owns 4 columns (c4) of rows er, er + 8, er + 16, er + 24
+    const int er = c.lane >> 3, c4 = (c.lane & 7) * 4, n = n0 + c4;
+    const bool ncol = n < cold.nstore;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gs = bv, gb = bv, rv[4] = {bv, bv, bv, bv};
+    if (ncol) {
+      if (cold.bias) bv = ldw4(cold.bias + (long long)p * cold.bias_pix_stride + n);
+      if (gn) { gs = ldw4(cold.gn_s + (long long)p * g.Npad + n); gb = ldw4(cold.gn_b1 + (long long)p * g.Npad + n); }
+      if (cold.R) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { const int bb = c.b0 + er + 8 * t; if (bb < c.B) rv[t] = ld4(cold.R + ((long long)hd.w * c.B + bb) * cold.ldr + n); }
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    auto run = [&](int lo, int hi) {
+      if (lo >= hi) return;
+      const int nk = hi - lo;
+      Frag f[PF];
+#pragma unroll
+      for (int sI = 0; sI < PF; ++sI) if (sI < nk) load_frag(f[sI], g, sload16(dsc + lo + sI), c.b0, c.B, c.lane, brow, fh);
+      for (int k = 0; k < nk; k += PF) {
+#pragma unroll
+        for (int sI = 0; sI < PF; ++sI) {
+          if (k + sI < nk) {
+            float av[16];
+            stage_frag(f[sI], tile, c.lane, av);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], f[sI].w[j], acc, 0, 0, 0);
+            if (k + sI + PF < nk) load_frag(f[sI], g, sload16(dsc + lo + k + sI + PF), c.b0, c.B, c.lane, brow, fh);
+          }
+        }
+      }
+    };
+    if (gn) {
+      run(0, n1);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] *= rr[r];
+      run(n1, total);
+    } else {
+      run(0, total);
+    }
+    // transpose through the wave's LDS tile (same wave: LDS is in order; the asm waits also stop compiler reordering)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * fh) * A_LD + fi] = acc[r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int row = er + 8 * t, bb = c.b0 + row;
+      const float4 tv = *reinterpret_cast<const float4*>(tile + row * A_LD + c4);
+      float v[4] = {tv.x, tv.y, tv.z, tv.w};
+      float s = 0.f, q = 0.f;
+      if (ncol && bb < c.B) {
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+        if (gn) {
+          const float2 mrv = c.mr[row]; const float mrs = mrv.x * mrv.y;
+          v[0] += gb.x - mrs * gs.x; v[1] += gb.y - mrs * gs.y; v[2] += gb.z - mrs * gs.z; v[3] += gb.w - mrs * gs.w;
+        }
+        v[0] += rv[t].x; v[1] += rv[t].y; v[2] += rv[t].z; v[3] += rv[t].w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = chain_act(cold.act, v[e]);
+        st4(g.out + ((long long)p * c.B + bb) * cold.ldo + n, make_float4(v[0], v[1], v[2], v[3]));
+        s = (v[0] + v[1]) + (v[2] + v[3]); q = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      }
+      if (cold.stat_out) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+        if ((c.lane & 7) == 0 && bb < c.B) cold.stat_out[((long long)p * nblk + nb) * c.B + bb] = make_float2(s, q);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // tile reads done before the next unit stages into it
+  }
+}
+
 DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
   TR(0);
   const GemmHot g = uniform_copy(m.g);
@@ -216,6 +309,7 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
     for (int r2 = 0; r2 < 16; ++r2) rr[r2] = c.mr[(r2 & 3) + 8 * (r2 >> 2) + 4 * fh].y;
   }
   TR(1);
+  if (__builtin_amdgcn_readfirstlane(m.wpu)) { TR(1); chain_gemm_wpu(g, cold, P, gn, c); TR(4); return; }
   float* atile = c.smem + c.wave * 32 * A_LD;
   const int units = P * nblk;
   const int row = (c.tid >> 3) & 31, c4 = (c.tid & 7) * 4;       // epilogue: threads 0..255 own 4 columns of one row

@@ -46,6 +46,7 @@ struct ChainGemm {
   unsigned tapmask;          // weight taps source 1 actually reads (zero-padding taps never are): prefetch hint
   int tap_floats;            // floats per tap block = Npad * Kp
   int w2_floats;             // floats of the source-2 weight block (0 if none)
+  int wpu;                   // 1: short K (<= 8 chunks per unit): one unit per WAVE, no K split (chain.hip chain_gemm_wpu)
   int rounds;                // unit schedule for a 32-workgroup cluster: sched[r * 32 + slot] = unit or -1, r < rounds
   const int* sched;          // (longest-processing-time assignment by chunk count; null -> plain striding)
 };
