@@ -200,11 +200,25 @@ def main():
                 kern[name] = dict(kernel=label, launches_per_forward=k["launches"], avg_launch_us=1e3 * k["ms"] / k["launches"], ms_per_forward=k["ms"],
                                   dense_gemm_flop_per_forward=fl, achieved=fl / (k["ms"] * 1e-3) / 1e12)
         dom = max(kern, key=lambda n: kern[n]["ms_per_forward"])
+        # HBM-side traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs of
+        # tools/traffic_probe.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; unit KB)
+        traffic = None
+        try:
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")) as fh:
+                tj = json.load(fh)
+            rows = [v for k, v in tj.items() if dom in k]
+            fetch = sum(r["FETCH_SIZE"]["avg_per_launch_raw"] * r["FETCH_SIZE"]["launches"] for r in rows)
+            write = sum(r["WRITE_SIZE"]["avg_per_launch_raw"] * r["WRITE_SIZE"]["launches"] for r in rows)
+            n = sum(r["FETCH_SIZE"]["launches"] for r in rows)
+            traffic = (2.0 * fetch + write) * 1024.0 / n
+        except Exception as exc:                       # the profile file is optional
+            log(f"no PMC traffic summary: {exc}")
         _, _, loop_ms = one_pass(score, decs, sde, x0, 7, start, device, timing=True)
         fwd_ms = sum(v["ms"] for v in prof.values())
         line["roofline"] = {
             "bound": "mfma", "achieved": kern[dom]["achieved"], "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": kern[dom]["achieved"] / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "frac": kern[dom]["achieved"] / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_note": "bytes per launch at the L2's memory side (Infinity-Cache hits included), rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json",
             "kernel": kern[dom]["kernel"], "launches_per_forward": kern[dom]["launches_per_forward"],
             "avg_launch_us": kern[dom]["avg_launch_us"], "dense_flop_per_launch": kern[dom]["dense_gemm_flop_per_forward"] / kern[dom]["launches_per_forward"],
             "gemm_kernels": {n: {k: (round(v, 4) if isinstance(v, float) and k != "dense_gemm_flop_per_forward" else v) for k, v in d.items() if k != "kernel"} for n, d in kern.items()},
