@@ -35,7 +35,9 @@ struct sbm_model {
   // sampler scratch (score nets only)
   float* d_score = nullptr;
   float* d_norms = nullptr;
-  int* d_counter = nullptr;
+  int* d_counter = nullptr;       // StepCtl block (step counter first)
+  float* d_time_table = nullptr;  // [table_rows][cond_ld] time-path outputs for every step of the current sampler run
+  size_t time_table_floats = 0;
   hipStream_t own = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
 };
@@ -106,6 +108,7 @@ void sbm_model_destroy(sbm_model* m) {
   if (m->d_score) (void)hipFree(m->d_score);
   if (m->d_norms) (void)hipFree(m->d_norms);
   if (m->d_counter) (void)hipFree(m->d_counter);
+  if (m->d_time_table) (void)hipFree(m->d_time_table);
   if (m->ev_in) (void)hipEventDestroy(m->ev_in);
   if (m->ev_out) (void)hipEventDestroy(m->ev_out);
   if (m->ev_t0) (void)hipEventDestroy(m->ev_t0);
@@ -138,6 +141,11 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   if ((e = hipMemcpy(m->d_params, m->plan.params.data(), pbytes, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(params)", e); }
   if ((e = hipMemset(m->d_ws, 0, wbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemset(workspace)", e); }
   std::vector<float>().swap(m->plan.params);          // host copy no longer needed
+  if (kind == SBM_UNET || kind == SBM_UNET_OA) {
+    if ((e = hipMalloc(&m->d_counter, 64)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(counter)", e); }
+    (void)hipMemset(m->d_counter, 0, 64);
+    m->dp.ctl = reinterpret_cast<const StepCtl*>(m->d_counter);
+  }
   {
     // resolve every GEMM op into kernel arguments once; the cold halves live in device memory
     const size_t nops = m->plan.ops.size();
@@ -188,7 +196,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
         sched_at[i] = sched_all.size(); cops[i].gm.rounds = (int)rounds;
         for (size_t r = 0; r < rounds; ++r) for (int k = 0; k < 32; ++k) sched_all.push_back(r < bins[k].size() ? bins[k][r] : -1);
       }
-      else if (op.kind == OP_DWCONV7) cops[i].d = make_dw_args(op.dw, m->d_params, m->d_ws);
+      else if (op.kind == OP_DWCONV7) cops[i].d = make_dw_args(m->plan, op.dw, m->d_params, m->d_ws, m->dp.ctl);
       else if (op.kind == OP_LINATTN || op.kind == OP_ATTN) cops[i].a = make_attn_args(op.at, m->d_ws);
       else if (op.kind == OP_GN_RES) cops[i].r = make_gnres_args(op.gr, m->d_params, m->d_ws);
       else { sbm_model_destroy(m); return fail("sbm_model_create: op kind cannot run in the chain kernel (" + op.name + ")"); }
@@ -212,8 +220,6 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
     const size_t sbytes = (size_t)batch * m->plan.out_C * m->plan.out_H * m->plan.out_W * sizeof(float);
     if ((e = hipMalloc(&m->d_score, sbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(score)", e); }
     if ((e = hipMalloc(&m->d_norms, (size_t)batch * 2 * sizeof(float))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(norms)", e); }
-    if ((e = hipMalloc(&m->d_counter, 64)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(counter)", e); }
-    (void)hipMemset(m->d_counter, 0, 64);
   }
   if ((e = hipStreamCreateWithFlags(&m->own, hipStreamNonBlocking)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipStreamCreate", e); }
   (void)hipEventCreateWithFlags(&m->ev_in, hipEventDisableTiming); (void)hipEventCreateWithFlags(&m->ev_out, hipEventDisableTiming);
@@ -483,7 +489,7 @@ int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_
 
 // one full sampling step enqueued on `st` (graph-capturable: no allocation, no sync, step index read on device)
 static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sampler_cfg& c, const float* timesteps, const float* alphas, const float* noise,
-                                float* x, float* x_mean, hipStream_t st) {
+                                float* x, float* x_mean, hipStream_t st, bool time_table) {
   const Plan& P = m->plan;
   const int B = P.B, CHW = P.out_C * P.out_H * P.out_W;
   const int dps = 1 + (c.pc ? c.n_steps : 0);
@@ -493,6 +499,7 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
   a.x_out = x; a.mean_out = x_mean; a.norms = m->d_norms; a.seed = c.seed; a.sample_offset = c.sample_offset; a.B = B; a.CHW = CHW; a.sde = sp;
   a.noise_step_stride = (long long)dps * B * CHW;
   auto score_eval = [&]() -> const char* {
+    if (time_table) return run_plan(m->dp, x, tbuf, m->d_score, st, 1);     // the time path comes from the table
     launch_fill_time(tbuf, timesteps, m->d_counter, B, st);
     return run_plan(m->dp, x, tbuf, m->d_score, st);
   };
@@ -541,9 +548,32 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
   launch_set_counter(m->d_counter, first_step, st);
   hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
   const char* e = nullptr;
+  // Every sample of the loop shares the step's time: tabulate the time path (sinusoid, time MLP, per-block condition GEMM)
+  // for all N steps once, B steps per pass through the very same ops; the depthwise kernels then index the table by the
+  // step counter and the per-step launches of the time path disappear.
+  const bool time_table = m->plan.cond_off >= 0 && m->plan.time_off >= 0 && !std::getenv("SBM_NO_TIME_TABLE");
+  if (time_table) {
+    const int N = sde->N, B = m->plan.B, ld = m->plan.cond_ld;
+    const size_t need = (size_t)N * ld;
+    if (need > m->time_table_floats) {
+      if (m->d_time_table) (void)hipFree(m->d_time_table);
+      m->d_time_table = nullptr; m->time_table_floats = 0;
+      HIPCHK(hipMalloc(&m->d_time_table, need * sizeof(float)));
+      m->time_table_floats = need;
+    }
+    for (int k0 = 0; k0 < N; k0 += B) {
+      const int n = N - k0 < B ? N - k0 : B;
+      HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, timesteps + k0, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+      if ((e = run_plan(m->dp, x_inout, m->d_ws + m->plan.time_off, m->d_score, st, 2))) return fail(std::string("sbm_sampler_run: ") + e);
+      HIPCHK(hipMemcpyAsync(m->d_time_table + (size_t)k0 * ld, m->d_ws + m->plan.cond_off, sizeof(float) * (size_t)n * ld, hipMemcpyDeviceToDevice, st));
+    }
+    StepCtl h{}; h.step = 0; h.table_mode = 1; h.tab_ld = ld; h.pad = 0; h.table = m->d_time_table;
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(m->d_counter) + 4, reinterpret_cast<const char*>(&h) + 4, sizeof(StepCtl) - 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));                            // `h` is a stack object
+  }
   if (cfg->use_graph && n_run > 1) {
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st);
+    e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table);
     hipError_t ce = hipStreamEndCapture(st, &graph);
     if (e) { if (graph) (void)hipGraphDestroy(graph); return fail(std::string("sbm_sampler_run: ") + e); }
     if (ce != hipSuccess) return fail_hip("hipStreamEndCapture", ce);
@@ -552,9 +582,10 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t0, st));
   for (int i = 0; i < n_run; ++i) {
     if (exec) { hipError_t le = hipGraphLaunch(exec, st); if (le != hipSuccess) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); return fail_hip("hipGraphLaunch", le); } }
-    else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st))) return fail(std::string("sbm_sampler_run: ") + e);
+    else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table))) return fail(std::string("sbm_sampler_run: ") + e);
   }
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t1, st));
+  if (time_table) HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st));      // back to per-forward time inputs
   HIPCHK(hipEventRecord(m->ev_out, st));
   HIPCHK(hipStreamWaitEvent(caller, m->ev_out, 0));
   if (elapsed_ms || exec) {

@@ -452,7 +452,7 @@ DEVINL void chain_dw(const DwArgs& dsrc, Ctx& c) {
         const float4 bi = *reinterpret_cast<const float4*>(d.bias + ch);
         acc.x += bi.x; acc.y += bi.y; acc.z += bi.z; acc.w += bi.w;
         if (d.cond) {
-          const float4 cv = *reinterpret_cast<const float4*>(d.cond + (long long)b * d.cond_ld + ch);
+          const float4 cv = *reinterpret_cast<const float4*>(dw_cond_row(d, b) + ch);
           acc.x += cv.x; acc.y += cv.y; acc.z += cv.z; acc.w += cv.w;
         }
         *reinterpret_cast<float4*>(d.out + ((long long)p * d.B + b) * d.ldo + ch) = acc;

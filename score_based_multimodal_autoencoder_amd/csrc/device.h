@@ -30,13 +30,23 @@ struct GemmHot {
   unsigned long long* dbg;              // diagnostic cycle stamps (null in production)
 };
 
+// Sampler control block (device memory, one per score net): the step counter every per-step kernel reads, and the time-path
+// table -- in the sampling loop all samples share the step's time, so the time MLP and the per-block condition GEMM are
+// tabulated once for all N steps and the depthwise kernels index the table by the step counter.
+struct StepCtl { int step; int table_mode; int tab_ld; int pad; const float* table; };
 struct DwArgs {
   const float* in; float* out; const float* w; const float* bias; const float* cond; float2* stat;
-  int B, H, W, C, ldi, ldo, cond_ld, lanes, spb;   // lanes = threads per sample, spb = samples per block
+  const StepCtl* ctl;        // null for models without a sampler
+  int B, H, W, C, ldi, ldo, cond_ld, cond_col, lanes, spb;   // cond_col: column of this block inside a table row; lanes = threads per sample, spb = samples per block
 };
+// the row of time conditions sample b reads: its own row of the per-forward buffer, or the step's row of the table
+__device__ __forceinline__ const float* dw_cond_row(const DwArgs& d, int b) {
+  if (d.ctl && d.ctl->table_mode) return d.ctl->table + (long long)d.ctl->step * d.ctl->tab_ld + d.cond_col;
+  return d.cond + (long long)b * d.cond_ld;
+}
 struct AttnArgs { const float* qkv; float* out; int B, n, ldq, ldo, heads; float scale; };
 struct GnResArgs { const float* u; const float* x; float* out; const float2* part; const float* gamma; const float* beta; int B, P, C, ldu, ldx, ldo, nparts; float inv_count; };
-DwArgs make_dw_args(const DwOp& o, const float* prm, float* ws);
+DwArgs make_dw_args(const Plan& plan, const DwOp& o, const float* prm, float* ws, const StepCtl* ctl);
 AttnArgs make_attn_args(const AttnOp& o, float* ws);
 GnResArgs make_gnres_args(const GnResOp& o, const float* prm, float* ws);
 
@@ -75,13 +85,14 @@ struct DevPlan {
   const ChainOp* chain_ops = nullptr;   // device array, one entry per plan op (filled for chain ops)
   ChainSync* chain_sync = nullptr;
   int chain_grid = 256;
+  const StepCtl* ctl = nullptr;         // sampler control block (score nets)
 };
 const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st);
 const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, float* ws, const GemmCold* cold_dev, GemmHot* hot, GemmCold* cold);
 
 // Enqueue every op of the plan on `st`.  Returns nullptr or a static error string.  No allocation, no
 // synchronisation: safe to capture into a hipGraph.
-const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st);
+const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops = 0);   // time_ops: 0 all ops, 1 skip the time path, 2 only the time path
 const char* launch_op(const DevPlan& dp, int op_index, const float* ext_in, float* ext_out, hipStream_t st);
 
 extern unsigned long long* g_gemm_dbg;

@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const DwArgs d) {
       const float4 bi = *reinterpret_cast<const float4*>(d.bias + c);
       acc.x += bi.x; acc.y += bi.y; acc.z += bi.z; acc.w += bi.w;
       if (d.cond) {
-        const float4 cv = *reinterpret_cast<const float4*>(d.cond + (long long)b * d.cond_ld + c);
+        const float4 cv = *reinterpret_cast<const float4*>(dw_cond_row(d, b) + c);
         acc.x += cv.x; acc.y += cv.y; acc.z += cv.z; acc.w += cv.w;
       }
       *reinterpret_cast<float4*>(d.out + ((long long)p * d.B + b) * d.ldo + c) = acc;
@@ -886,8 +886,9 @@ const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, 
   return nullptr;
 }
 
-DwArgs make_dw_args(const DwOp& o, const float* prm, float* ws) {
+DwArgs make_dw_args(const Plan& plan, const DwOp& o, const float* prm, float* ws, const StepCtl* ctl) {
   DwArgs d{};
+  d.ctl = (o.has_cond && plan.cond_off >= 0) ? ctl : nullptr; d.cond_col = o.has_cond && plan.cond_off >= 0 ? (int)(o.cond_off - plan.cond_off) : 0;
   d.in = ws + o.in.off; d.out = ws + o.out.off; d.w = prm + o.w_off; d.bias = prm + o.bias_off;
   d.cond = o.has_cond ? ws + o.cond_off : nullptr; d.stat = o.stat_off >= 0 ? reinterpret_cast<float2*>(ws + o.stat_off) : nullptr;
   d.B = o.B; d.H = o.in.H; d.W = o.in.W; d.C = o.in.C; d.ldi = o.in.ld; d.ldo = o.out.ld; d.cond_ld = o.cond_ld;
@@ -931,7 +932,7 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
   switch (op.kind) {
     case OP_GEMM: return launch_gemm(op.g, dp.hot[idx], ext_in, ext_out, st);
     case OP_DWCONV7: {
-      const DwOp& o = op.dw; const DwArgs d = make_dw_args(o, prm, ws);
+      const DwOp& o = op.dw; const DwArgs d = make_dw_args(plan, o, prm, ws, dp.ctl);
       dim3 grid(o.in.H * o.in.W, ceil_div(o.B, d.spb));
       SBM_KLAUNCH(dwconv7_kernel, grid, dim3(256), 0, st, d);
     } break;
@@ -980,17 +981,19 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
   return nullptr;
 }
 
-const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st) {
+const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops) {
   const Plan& plan = *dp.plan;
   if (plan.time_off >= 0 && t_dev && t_dev != dp.ws + plan.time_off)
     if (hipMemcpyAsync(dp.ws + plan.time_off, t_dev, sizeof(float) * plan.B, hipMemcpyDeviceToDevice, st) != hipSuccess) return "time copy failed";
   if (plan.aux_off >= 0 && dp.aux)
     if (hipMemcpyAsync(dp.ws + plan.aux_off, dp.aux, sizeof(float) * plan.B * plan.aux_C, hipMemcpyDeviceToDevice, st) != hipSuccess) return "aux copy failed";
+  auto skipped = [&](int i) { return (time_ops == 1 && plan.ops[i].time_path) || (time_ops == 2 && !plan.ops[i].time_path); };
   for (int i = 0; i < (int)plan.ops.size();) {
     int n = 1;
     const char* e;
+    if (skipped(i)) { ++i; continue; }
     if (plan.ops[i].chain) {                        // a maximal run of chain ops is ONE launch
-      while (i + n < (int)plan.ops.size() && plan.ops[i + n].chain) ++n;
+      while (i + n < (int)plan.ops.size() && plan.ops[i + n].chain && !skipped(i + n)) ++n;
       e = launch_chain(dp, i, n, st);
     } else {
       e = launch_op(dp, i, ext_in, ext_out, st);

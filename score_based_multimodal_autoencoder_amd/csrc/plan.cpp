@@ -626,6 +626,8 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       op.flops = 2.0 * B * g.Npad * d.td;
       plan->flops_exec += op.flops;
       b.free_act(e2);   // ops run in stream order: e2 is dead once the GEMM above has executed
+      plan->cond_off = cond_off; plan->cond_ld = cond_ld;
+      for (Op& o : plan->ops) if (o.kind != OP_NCHW_TO_PBC) o.time_path = 1;      // everything emitted so far except the input conversion
     }
     const size_t cond_op_index = plan->ops.size() - 1;
     std::vector<float> cond_w, cond_b;

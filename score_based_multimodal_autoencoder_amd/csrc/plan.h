@@ -136,6 +136,7 @@ struct Op {
   std::string name;       // reference layer this op implements (for profiles and error messages)
   double flops = 0;       // 2*MAC this op issues (padding taps skipped, channel padding included)
   double flops_dense = 0; // GEMM ops: 2*MAC in the dense convention (zero-padding taps counted), the roofline numerator
+  int time_path = 0;      // 1: depends on the time input only (sinusoid, time MLP, per-block condition GEMM): the sampler tabulates it
   int chain = 0;          // 1: runs inside the XCD-resident chain kernel (low-resolution ops; GEMM tile 32x32) -- chain.hip
   GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf; Gn32Op gn; AttnQkvOp aq;
 };
@@ -156,6 +157,7 @@ struct Plan {
   int out_C = 0, out_H = 0, out_W = 0;
   int needs_time = 0;
   int64_t time_off = -1;         // workspace [B] : the plan's time input is copied here
+  int64_t cond_off = -1; int cond_ld = 0;   // workspace [B][cond_ld]: output of the time path (per-block time conditions), -1 if none
   int64_t aux_off = -1; int aux_C = 0;   // workspace [B][aux_C]: auxiliary conditioning input (UNetModel z), copied before a run
   double flops_dense = 0;        // 2*MAC, dense convention (zero-padding taps counted)
   double flops_exec = 0;         // 2*MAC actually issued (padding taps skipped, channel padding included)
