@@ -546,6 +546,10 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
   HIPCHK(hipEventRecord(m->ev_in, caller));
   HIPCHK(hipStreamWaitEvent(st, m->ev_in, 0));
   launch_set_counter(m->d_counter, first_step, st);
+  struct TableModeGuard {      // whatever happens below, later forwards read their own time inputs again
+    sbm_model* m; hipStream_t st; bool armed = false;
+    ~TableModeGuard() { if (armed) { (void)hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st); (void)hipStreamSynchronize(st); } }
+  } guard{m, st};
   hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
   const char* e = nullptr;
   // Every sample of the loop shares the step's time: tabulate the time path (sinusoid, time MLP, per-block condition GEMM)
@@ -570,6 +574,7 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
     StepCtl h{}; h.step = 0; h.table_mode = 1; h.tab_ld = ld; h.pad = 0; h.table = m->d_time_table;
     HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(m->d_counter) + 4, reinterpret_cast<const char*>(&h) + 4, sizeof(StepCtl) - 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipStreamSynchronize(st));                            // `h` is a stack object
+    guard.armed = true;
   }
   if (cfg->use_graph && n_run > 1) {
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -585,7 +590,7 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
     else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table))) return fail(std::string("sbm_sampler_run: ") + e);
   }
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t1, st));
-  if (time_table) HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st));      // back to per-forward time inputs
+  if (time_table) { HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st)); guard.armed = false; }      // back to per-forward time inputs
   HIPCHK(hipEventRecord(m->ev_out, st));
   HIPCHK(hipStreamWaitEvent(caller, m->ev_out, 0));
   if (elapsed_ms || exec) {

@@ -142,8 +142,8 @@ DEVINL bool cluster_barrier(Ctx& c, const ChainOp* next) {
   if (c.tid == 0) {
     unsigned spins = 0, ok = 1;
     while (ctr_load(c.bar) < c.gen) {
-      if (++spins > SPIN_LIMIT || ctr_load(&c.sync->abort_flag)) { (void)__hip_atomic_exchange(&c.sync->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
-      __builtin_amdgcn_s_sleep(1);
+      if (++spins > SPIN_LIMIT) { (void)__hip_atomic_exchange(&c.sync->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      if ((spins & 1023u) == 0 && ctr_load(&c.sync->abort_flag)) { ok = 0; break; }
     }
     *c.flag = ok;
   }

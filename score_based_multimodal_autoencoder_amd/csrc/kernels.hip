@@ -623,6 +623,70 @@ __global__ __launch_bounds__(64) void linattn_lds_kernel(const AttnArgs a) {
   }
 }
 
+// 16 < n <= 64: four waves per (sample, head).  q/k/v staged once in LDS; every wave forms the k-softmax statistics (cheap,
+// redundant), accumulates the context over its quarter of the pixels, the four partial contexts are added in wave order,
+// and each wave then produces its quarter of the output pixels.
+__global__ __launch_bounds__(256) void linattn_lds4_kernel(const AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) float sq[64 * 32], sk[64 * 32], sv[64 * 32];      // [pixel][d]
+  __shared__ float pctx[4][32][33];
+  __shared__ float qs[4][2][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+  const int hd = a.heads * 32;
+  const float* base = a.qkv + (long long)b * a.ldq + h * 32;
+  const long long pstride = (long long)a.B * a.ldq;
+  for (int idx = tid; idx < a.n * 8; idx += 256) {
+    const int i = idx >> 3, c4 = (idx & 7) * 4;
+    const float* r = base + i * pstride + c4;
+    reinterpret_cast<float4*>(sq)[idx] = *reinterpret_cast<const float4*>(r);
+    reinterpret_cast<float4*>(sk)[idx] = *reinterpret_cast<const float4*>(r + hd);
+    reinterpret_cast<float4*>(sv)[idx] = *reinterpret_cast<const float4*>(r + 2 * hd);
+  }
+  __syncthreads();
+  float kmax = -INFINITY;
+  for (int i = half; i < a.n; i += 2) kmax = fmaxf(kmax, sk[i * 32 + d]);
+  kmax = fmaxf(kmax, __shfl_xor(kmax, 32));
+  float ksum = 0.f;
+  for (int i = half; i < a.n; i += 2) ksum += expf(sk[i * 32 + d] - kmax);
+  ksum += __shfl_xor(ksum, 32);
+  const float kinv = 1.0f / ksum;
+  const int per = (a.n + 3) / 4, i_lo = wave * per, i_hi = min(a.n, i_lo + per);
+  float c[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c[e] = 0.f;
+  for (int i = i_lo; i < i_hi; ++i) {
+    const float kv = expf(sk[i * 32 + d] - kmax) * kinv;
+    const float* vrow = sv + i * 32 + half * 16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = fmaf(kv, vrow[e], c[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) pctx[wave][d][half * 16 + e] = c[e];
+  __syncthreads();
+  float col[32];
+#pragma unroll
+  for (int dd = 0; dd < 32; ++dd) col[dd] = ((pctx[0][dd][d] + pctx[1][dd][d]) + pctx[2][dd][d]) + pctx[3][dd][d];
+  for (int i0 = i_lo; i0 < i_hi; i0 += 2) {
+    const int i = i0 + half;
+    const bool ok = i < i_hi;
+    const float qv = ok ? sq[i * 32 + d] : 0.f;
+    float m = qv;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float e = expf(qv - m);
+    float s = e;
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    qs[wave][half][d] = e / s * a.scale;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private exchange: LDS is in order within a wave
+    float o = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) o = fmaf(col[dd], qs[wave][half][dd], o);
+    if (ok) a.out[((long long)i * a.B + b) * a.ldo + h * 32 + d] = o;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // softmax attention core (unet_model.py:141-148), n <= 64: one wave per (sample, head); lane = query i
 __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   __shared__ float sk[32][65], sv[32][65];
@@ -940,7 +1004,8 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       const AttnOp& o = op.at; const AttnArgs a = make_attn_args(o, ws);
       if (o.dh != 32) return "attention: dim_head must be 32";
       if (op.kind == OP_ATTN && a.n > 64) return "softmax attention: more than 64 positions";
-      if (op.kind == OP_LINATTN && a.n <= 64 && (a.ldq & 3) == 0) SBM_KLAUNCH(linattn_lds_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
+      if (op.kind == OP_LINATTN && a.n > 16 && a.n <= 64 && (a.ldq & 3) == 0) SBM_KLAUNCH(linattn_lds4_kernel, dim3(o.B * o.heads), dim3(256), 0, st, a);
+      else if (op.kind == OP_LINATTN && a.n <= 64 && (a.ldq & 3) == 0) SBM_KLAUNCH(linattn_lds_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
       else if (op.kind == OP_LINATTN) SBM_KLAUNCH(linattn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
       else SBM_KLAUNCH(attn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
     } break;

@@ -332,3 +332,58 @@ def test_unet_openai_matches_reference(pkg, golden, name):
     assert_close(y, g[f"{name}_y"], 1e-5, 1e-5 * np.abs(g[f"{name}_y"]).max(), name)
     y0 = m(dev(g[f"{name}_x"]), dev(g[f"{name}_t"])).cpu().numpy()
     assert_close(y0, g[f"{name}_y_noz"], 1e-5, 1e-5 * np.abs(g[f"{name}_y_noz"]).max(), name + " (z=None)")
+
+
+# ------------------------------------------------------------------------------------------------
+# chain kernel / time table: the fast paths against the plain per-layer path of the same library
+def _sampler_run(pkg, m, x0, N, seed, **env):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        m.release_engines()
+        sde = pkg["sde"].VPSDE(0.1, 5.0, N)
+        return pkg["sde"].uncond_sampler(tuple(x0.shape), m, "cuda", sde, x0=x0, seed=seed)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        m.release_engines()
+
+
+def test_time_table_is_bit_identical_to_per_step_time_path(pkg):
+    """Tabulating the time MLP for all steps must not change a single bit of the trajectory."""
+    m = _unet(pkg, "tiny")
+    x0 = torch.randn(5, 2, 8, 8, device="cuda")
+    a = _sampler_run(pkg, m, x0, 50, 3)
+    b = _sampler_run(pkg, m, x0, 50, 3, SBM_NO_TIME_TABLE=1)
+    assert torch.equal(a, b)
+
+
+def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
+    """Config-2 score net, B=256 (8 sample tiles = 8 XCD clusters): XCD-resident chain vs one launch per layer."""
+    import ctypes
+    m = _unet(pkg, "P5")
+    x = torch.randn(256, 5, 8, 8, device="cuda")
+    t = torch.rand(256, device="cuda")
+    import os
+    outs = {}
+    for pix in ("0", "16"):
+        os.environ["SBM_CHAIN_PIX"] = pix
+        try:
+            m.release_engines()
+            for _ in range(3):
+                y = m(x, t)
+            outs[pix] = y.clone()
+            eng = m._engine_for(256, 8, 8)
+            st = (ctypes.c_uint * 300)()
+            pkg["lib"].check(pkg["lib"].lib().sbm_debug_chain_sync(eng.h, st, 300))
+            assert not any(st), "chain synchronisation state must be clean between launches (no abort, counters reset)"
+        finally:
+            os.environ.pop("SBM_CHAIN_PIX", None)
+            m.release_engines()
+    scale = float(outs["0"].abs().max())
+    assert float((outs["0"] - outs["16"]).abs().max()) <= 2e-5 * scale
+    assert torch.isfinite(outs["16"]).all()
