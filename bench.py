@@ -189,9 +189,9 @@ def main():
         xs = x0.clone()
         tt = torch.ones(B_PER_GPU, device=device) * 0.5
         so = torch.empty_like(xs)
-        prof = eng.profile(xs, tt, so, reps=20)
+        prof = eng.profile(xs, tt, so, reps=20, sampler_mix=True)      # the launches one SDE step of the timed loop makes
         log("per-kernel profile done")
-        f_seg, f_chain = eng.gemm_flops()
+        f_seg, f_chain = eng.gemm_flops(sampler_mix=True)
         kern = {}
         for name, label, fl in (("seg_gemm", "seg_gemm<BM,BN> (fp32 MFMA implicit-GEMM conv, one launch per 8x8 layer)", f_seg),
                                 ("chain_kernel", "chain_kernel (XCD-resident run of the 4x4/2x2/1x1 layers: fp32 MFMA GEMMs + dwconv/attention/GroupNorm glue)", f_chain)):

@@ -87,8 +87,13 @@ int sbm_model_set_aux(sbm_model* m, const float* aux_dev);
  * 1 = dwconv7, 2 = linattn, 3 = attn, 4 = gn_res, 5 = sinus, 6 = nchw_to_pbc, 7 = bilinear); sums per forward. */
 int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps,
                       double* ms_by_kind, int* launches_by_kind, int n_kinds);
-/* Dense-convention GEMM FLOP per forward executed by seg_gemm launches (out2[0]) and by chain_kernel launches (out2[1]). */
-int sbm_model_gemm_flops(const sbm_model* m, double* out2);
+/* As sbm_model_profile; sampler_mix != 0 times the launch mix of one step of sbm_sampler_run (the time path -- sinusoid, time MLP,
+ * per-block condition GEMM -- is tabulated once per run there and not launched per step). */
+int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, int sampler_mix,
+                          double* ms_by_kind, int* launches_by_kind, int n_kinds);
+/* Dense-convention GEMM FLOP per forward executed by seg_gemm launches (out4[0]) and by chain_kernel launches (out4[1]);
+ * out4[2], out4[3]: the parts of those that belong to the time path (tabulated once per sampler run, not launched per step). */
+int sbm_model_gemm_flops(const sbm_model* m, double* out4);
 
 /* SDE description == the reference's SDE objects (sde_helper2.py:329-473). kind: 0 VPSDE, 1 subVPSDE, 2 VESDE;
  * (b0,b1) = (beta_min,beta_max) or (sigma_min,sigma_max). */

@@ -19,7 +19,7 @@ OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "n
                  "attn_qkv", "chain_kernel"]
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
-           "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step",
+           "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step",
            "sbm_fill_normal", "sbm_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_stamps"]
 
@@ -80,6 +80,7 @@ def lib():
         L.sbm_model_forward_aux.argtypes = [vp, vp, vp, vp, vp, vp]
         L.sbm_model_set_aux.argtypes = [vp, vp]
         L.sbm_model_profile.argtypes = [vp, vp, vp, vp, i, ctypes.POINTER(dbl), ip, i]
+        L.sbm_model_profile_mix.argtypes = [vp, vp, vp, vp, i, i, ctypes.POINTER(dbl), ip, i]
         L.sbm_model_gemm_flops.argtypes = [vp, ctypes.POINTER(dbl)]
         L.sbm_em_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, vp]
         L.sbm_langevin_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
@@ -196,19 +197,20 @@ class Engine:
                                           out.data_ptr(), stream_ptr()))
         return out
 
-    def profile(self, x, t, out, reps=5):
+    def profile(self, x, t, out, reps=5, sampler_mix=False):
+        """Per-kernel time of one forward; sampler_mix: the launch mix of one step of the sampling loop."""
         n = len(OP_KIND_NAMES)
         ms = (ctypes.c_double * n)()
         cnt = (ctypes.c_int * n)()
-        check(lib().sbm_model_profile(self.h, x.data_ptr(), t.data_ptr() if t is not None else None, out.data_ptr(), reps,
-                                      ms, cnt, n))
+        check(lib().sbm_model_profile_mix(self.h, x.data_ptr(), t.data_ptr() if t is not None else None, out.data_ptr(), reps,
+                                          int(bool(sampler_mix)), ms, cnt, n))
         return {OP_KIND_NAMES[k]: dict(ms=ms[k], launches=cnt[k]) for k in range(n)}
 
-    def gemm_flops(self):
-        """(dense GEMM FLOP per forward run by seg_gemm launches, ... by chain_kernel launches)"""
-        v = (ctypes.c_double * 2)()
+    def gemm_flops(self, sampler_mix=False):
+        """(dense GEMM FLOP per forward run by seg_gemm launches, ... by chain_kernel launches); sampler_mix: without the time path"""
+        v = (ctypes.c_double * 4)()
         check(lib().sbm_model_gemm_flops(self.h, v))
-        return v[0], v[1]
+        return (v[0] - v[2], v[1] - v[3]) if sampler_mix else (v[0], v[1])
 
     def close(self):
         if getattr(self, "h", None):

@@ -378,7 +378,13 @@ int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev,
 // Launches are issued exactly as run_plan issues them (a run of chain ops = ONE chain_kernel launch) and each carries its
 // own event pair; bucket k < 11 = op kind k launched as its own kernel, bucket 11 = chain_kernel.
 int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, double* ms_by_kind, int* launches_by_kind, int n_kinds) {
+  return sbm_model_profile_mix(m, in_dev, t_dev, out_dev, reps, 0, ms_by_kind, launches_by_kind, n_kinds);
+}
+
+// sampler_mix != 0: the launch mix of one step of sbm_sampler_run, where the time path comes from the per-run table and is not launched
+int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, int sampler_mix, double* ms_by_kind, int* launches_by_kind, int n_kinds) {
   if (!m || !in_dev || !out_dev || reps <= 0 || !ms_by_kind || !launches_by_kind) return fail("sbm_model_profile: bad arguments");
+  const bool skip_time = sampler_mix && m->plan.cond_off >= 0 && !std::getenv("SBM_NO_TIME_TABLE");
   for (int k = 0; k < n_kinds; ++k) { ms_by_kind[k] = 0; launches_by_kind[k] = 0; }
   hipStream_t st = m->own;
   const char* e = run_plan(m->dp, in_dev, t_dev, out_dev, st);       // warm-up
@@ -393,10 +399,11 @@ int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, flo
     bucket.clear();
     for (int i = 0; i < nops;) {
       int n = 1;
+      if (skip_time && m->plan.ops[i].time_path) { ++i; continue; }
       const size_t l = bucket.size();
       arm_profile_events(ev[2 * l], ev[2 * l + 1]);            // events ride on the kernel's own dispatch: begin -> end of the kernel
       if (m->plan.ops[i].chain) {
-        while (i + n < nops && m->plan.ops[i + n].chain) ++n;
+        while (i + n < nops && m->plan.ops[i + n].chain && !(skip_time && m->plan.ops[i + n].time_path)) ++n;
         if (n > CHAIN_MAX_OPS) n = CHAIN_MAX_OPS;              // one launch per event pair
         e = launch_chain(m->dp, i, n, st);
         bucket.push_back(11);
@@ -420,12 +427,17 @@ int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, flo
 }
 
 // Dense-convention GEMM FLOP (2*MAC, zero-padding taps counted) per forward, split by the kernel that executes them:
-// out[0] = seg_gemm launches, out[1] = chain_kernel launches.
-int sbm_model_gemm_flops(const sbm_model* m, double* out2) {
-  if (!m || !out2) return fail("sbm_model_gemm_flops: bad arguments");
-  double chain = 0.0;
-  for (const Op& op : m->plan.ops) if (op.kind == OP_GEMM && op.chain) chain += op.flops_dense;
-  out2[0] = m->plan.flops_dense_gemm - chain; out2[1] = chain;
+// out[0] = seg_gemm launches, out[1] = chain_kernel launches; out[2], out[3] = the parts of out[0], out[1] that belong to the
+// time path (not launched per step inside sbm_sampler_run).
+int sbm_model_gemm_flops(const sbm_model* m, double* out4) {
+  if (!m || !out4) return fail("sbm_model_gemm_flops: bad arguments");
+  double chain = 0.0, chain_t = 0.0, seg_t = m->plan.flops_dense_cond;
+  for (const Op& op : m->plan.ops) {
+    if (op.kind != OP_GEMM) continue;
+    if (op.chain) { chain += op.flops_dense; if (op.time_path) chain_t += op.flops_dense; }
+    else if (op.time_path) seg_t += op.flops_dense;
+  }
+  out4[0] = m->plan.flops_dense_gemm - chain; out4[1] = chain; out4[2] = seg_t; out4[3] = chain_t;
   return 0;
 }
 

@@ -642,7 +642,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
         std::memcpy(&cond_w[(size_t)(col + cm.idx[c]) * td_p], &w[(size_t)c * d.td], sizeof(float) * d.td);
         cond_b[col + cm.idx[c]] = bb[c];
       }
-      plan->flops_dense += 2.0 * B * cin * d.td; plan->flops_dense_gemm += 2.0 * B * cin * d.td;
+      plan->flops_dense += 2.0 * B * cin * d.td; plan->flops_dense_gemm += 2.0 * B * cin * d.td; plan->flops_dense_cond += 2.0 * B * cin * d.td;
     };
 
     // init conv 7x7

@@ -161,7 +161,8 @@ struct Plan {
   int64_t aux_off = -1; int aux_C = 0;   // workspace [B][aux_C]: auxiliary conditioning input (UNetModel z), copied before a run
   double flops_dense = 0;        // 2*MAC, dense convention (zero-padding taps counted)
   double flops_exec = 0;         // 2*MAC actually issued (padding taps skipped, channel padding included)
-  double flops_dense_gemm = 0;   // the part of flops_dense computed by seg_gemm launches
+  double flops_dense_gemm = 0;   // the part of flops_dense computed by GEMM ops
+  double flops_dense_cond = 0;   // ... of which the per-block time-condition GEMM (a time-path op emitted directly)
   int64_t ident_off = -1;        // params: 32 ones followed by 32 zeros (identity gamma/beta for chunks without GroupNorm)
   std::string error;
 };
