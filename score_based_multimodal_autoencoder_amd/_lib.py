@@ -14,9 +14,9 @@ LIB_PATH = os.path.join(CSRC, "libsbmae_hip.so")
 SOURCES = ["plan.cpp", "kernels.hip", "chain.hip", "sampler.hip", "api.hip"]
 HEADERS = ["plan.h", "device.h", os.path.join("..", "..", "include", "sbmae.h")]
 
-SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA, SBM_MLP = 0, 1, 2, 3, 4
+SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA, SBM_MLP, SBM_RESENC = 0, 1, 2, 3, 4, 5
 OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "nchw_to_pbc", "bilinear", "gn_final", "gn32",
-                 "attn_qkv", "chain_kernel"]
+                 "attn_qkv", "chain_kernel", "avgpool"]
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
            "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step",

@@ -34,6 +34,7 @@ DEVINL float chain_act(int act, float v) {
     case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     case ACT_SILU: return v / (1.0f + expf(-v));
     case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
+    case ACT_LRELU01: return v >= 0.f ? v : 0.1f * v;
     default: return v;
   }
 }

@@ -24,6 +24,7 @@ static inline float act_apply(int act, float v) {
     case ACT_SIGMOID: return (float)(1.0 / (1.0 + std::exp(-(double)v)));
     case ACT_SILU: return (float)((double)v / (1.0 + std::exp(-(double)v)));
     case ACT_SOFTPLUS: return v > 20.f ? v : (float)std::log1p(std::exp((double)v));
+    case ACT_LRELU01: return v >= 0.f ? v : 0.1f * v;
     default: return v;
   }
 }
@@ -229,6 +230,14 @@ void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const 
         }
       } break;
       case OP_BILINEAR: run_bilinear(op.bl, ws.data()); break;
+      case OP_AVGPOOL: {
+        const BilinearOp& o = op.bl; const int k = o.scale, Ho = o.out.H, Wo = o.out.W, Wi = o.in.W;
+        for (int oy = 0; oy < Ho; ++oy) for (int ox = 0; ox < Wo; ++ox) for (int b = 0; b < o.B; ++b) for (int c = 0; c < o.in.C; ++c) {
+          float s = 0.f;
+          for (int i = 0; i < k; ++i) for (int j = 0; j < k; ++j) s += ws[o.in.off + ((int64_t)((oy * k + i) * Wi + ox * k + j) * o.B + b) * o.in.ld + c];
+          ws[o.out.off + ((int64_t)(oy * Wo + ox) * o.B + b) * o.out.ld + c] = s / (float)(k * k);
+        }
+      } break;
       case OP_GN32: {
         const Gn32Op& o = op.gn; const int P = o.in.H * o.in.W, C = o.in.C, cg = C / o.groups;
         for (int b = 0; b < o.B; ++b) for (int g = 0; g < o.groups; ++g) {
@@ -314,6 +323,7 @@ void* sbmref_build(int kind, const int* cfg, int B, int z_ld, const float* const
   else if (kind == 2) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, B, z_ld, tensors, &h->plan); }
   else if (kind == 3) ok = build_unet_oa_plan(unet_oa_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);
   else if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; ok = build_mlp_plan(c, B, tensors, &h->plan); }
+  else if (kind == 5) ok = build_resenc_plan(resdec_cfg_from_ints(cfg), B, tensors, &h->plan);
   if (!ok) { g_err = h->plan.error.empty() ? "unknown plan kind" : h->plan.error; delete h; return nullptr; }
   h->ws.assign((size_t)h->plan.ws_floats, std::nanf(""));      // poison: every read must be preceded by a write
   return h;
@@ -324,6 +334,7 @@ int sbmref_num_specs(int kind, const int* cfg) {
   if (kind == 1) return (int)resdec_tensor_specs(resdec_cfg_from_ints(cfg)).size();
   if (kind == 3) return (int)unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg)).size();
   if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; return (int)mlp_tensor_specs(c).size(); }
+  if (kind == 5) return (int)resenc_tensor_specs(resdec_cfg_from_ints(cfg)).size();
   AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1];
   return (int)attrdec_tensor_specs(a).size();
 }
@@ -334,6 +345,7 @@ long sbmref_spec(int kind, const int* cfg, int i, char* name, int cap) {
   else if (kind == 1) s = resdec_tensor_specs(resdec_cfg_from_ints(cfg));
   else if (kind == 3) s = unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg));
   else if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; s = mlp_tensor_specs(c); }
+  else if (kind == 5) s = resenc_tensor_specs(resdec_cfg_from_ints(cfg));
   else { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; s = attrdec_tensor_specs(a); }
   if (i < 0 || i >= (int)s.size()) return -1;
   std::strncpy(name, s[i].name.c_str(), cap - 1); name[cap - 1] = 0;

@@ -43,6 +43,7 @@ DEVINL float act_apply(int act, float v) {
     case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     case ACT_SILU: return v / (1.0f + expf(-v));
     case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));      // nn.Softplus(beta=1, threshold=20)
+    case ACT_LRELU01: return v >= 0.f ? v : 0.1f * v;
     default: return v;
   }
 }
@@ -912,6 +913,24 @@ __global__ void bilinear_kernel(const BilArgs o) {
   *reinterpret_cast<float4*>(o.out + ((long long)p * o.B + b) * o.ldo + c) = v;
 }
 
+// AvgPool2d(k), PBC -> PBC (encoders, h_vae_model_copy.py:52, 31): the k*k inputs are summed in row-major window order
+__global__ void avgpool_kernel(const BilArgs o) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4n = o.C / 4, k = o.scale;
+  const long long total = (long long)o.Ho * o.Wo * o.B * c4n;
+  if (idx >= total) return;
+  const int c = (idx % c4n) * 4; long long r = idx / c4n; const int b = r % o.B; const int p = r / o.B;
+  const int oy = p / o.Wo, ox = p - oy * o.Wo;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 0; i < k; ++i)
+    for (int j = 0; j < k; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(o.in + ((long long)((oy * k + i) * o.Wi + ox * k + j) * o.B + b) * o.ldi + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  const float d = (float)(k * k);
+  *reinterpret_cast<float4*>(o.out + ((long long)p * o.B + b) * o.ldo + c) = make_float4(s.x / d, s.y / d, s.z / d, s.w / d);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
@@ -1026,6 +1045,12 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       a.in = ws + o.in.off; a.out = ws + o.out.off; a.B = o.B; a.Hi = o.in.H; a.Wi = o.in.W; a.Ho = o.out.H; a.Wo = o.out.W; a.C = o.in.C; a.ldi = o.in.ld; a.ldo = o.out.ld; a.scale = o.scale;
       const long long n = (long long)a.Ho * a.Wo * a.B * (a.C / 4);
       SBM_KLAUNCH(bilinear_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+    } break;
+    case OP_AVGPOOL: {
+      const BilinearOp& o = op.bl; BilArgs a{};
+      a.in = ws + o.in.off; a.out = ws + o.out.off; a.B = o.B; a.Hi = o.in.H; a.Wi = o.in.W; a.Ho = o.out.H; a.Wo = o.out.W; a.C = o.in.C; a.ldi = o.in.ld; a.ldo = o.out.ld; a.scale = o.scale;
+      const long long n = (long long)a.Ho * a.Wo * a.B * (a.C / 4);
+      SBM_KLAUNCH(avgpool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
     } break;
     case OP_GN32: {
       const Gn32Op& o = op.gn; Gn32Args a{};

@@ -125,6 +125,20 @@ std::vector<TensorSpec> resdec_tensor_specs(const ResDecCfg& c) {
   return L.v;
 }
 
+std::vector<TensorSpec> resenc_tensor_specs(const ResDecCfg& c) {
+  SpecList L;
+  const int c0 = c.enc[0][0];
+  L.add("enc.ch_enc.0.weight", {c0, c.img_ch, 5, 5}); L.add("enc.ch_enc.0.bias", {c0});
+  L.add("enc.ch_enc.1.weight", {c0}); L.add("enc.ch_enc.1.bias", {c0}); L.add("enc.ch_enc.1.running_mean", {c0}); L.add("enc.ch_enc.1.running_var", {c0});
+  for (int i = 0; i < c.n_enc; ++i) spec_rblock(L, "enc.r_blocks." + std::to_string(i) + ".", c.enc[i][0], c.enc[i][1], c.enc[i][2]);
+  int s = c.size_in / 2;
+  for (int i = 0; i < c.n_enc; ++i) s /= c.enc[i][3];
+  const int64_t lin = (int64_t)s * s * (c.enc[c.n_enc - 1][2] / 2);
+  L.add("enc.mu_lin.weight", {c.size_z, lin}); L.add("enc.mu_lin.bias", {c.size_z});
+  L.add("enc.logvar_lin.weight", {c.size_z, lin}); L.add("enc.logvar_lin.bias", {c.size_z});
+  return L.v;
+}
+
 static const int kAttrW[5] = {512, 512, 512, 256, 128};
 
 std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& c) {
@@ -1172,6 +1186,62 @@ bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const
     if (o.H != cfg.size_in) throw std::runtime_error("plan: decoder geometry does not reach size_in");
     b.emit_conv(fc);
     b.free_act(o);
+    finalize_gemm_tables(plan);
+    return true;
+  } catch (const std::exception& e) {
+    plan->error = e.what();
+    return false;
+  }
+}
+
+// ResEncoder / ResEncoderN (h_vae_model_copy.py:41-71, 379-409): conv5x5+BN+LeakyReLU -> AvgPool2 -> RBlocks (each followed
+// by AvgPool(down)) -> channel halves -> mu_lin / logvar_lin on the flattened (c, y, x) features.  The two Linears are one
+// full-image convolution with block-structured weights; output rows are [mu | logvar].
+bool build_resenc_plan(const ResDecCfg& cfg, int B, const float* const* tensors, Plan* plan) {
+  try {
+    std::vector<TensorSpec> specs = resenc_tensor_specs(cfg);
+    Builder b(plan, B, specs, tensors);
+    const bool nvar = cfg.variant != 0;
+    plan->in_C = cfg.img_ch; plan->in_H = plan->in_W = cfg.size_in; plan->in_ld = 0;
+    plan->out_C = 2 * cfg.size_z; plan->out_H = plan->out_W = 1;
+    View xin = b.new_act(cfg.size_in, cfg.size_in, cfg.img_ch);
+    { Op& op = b.push(OP_NCHW_TO_PBC, "input"); op.cv.B = B; op.cv.C = cfg.img_ch; op.cv.Hn = cfg.size_in; op.cv.Wn = cfg.size_in; op.cv.out = xin; }
+    const int c0 = cfg.enc[0][0];
+    std::vector<double> s0, t0;
+    bn_fold(b, "enc.ch_enc.1.", c0, &s0, &t0);
+    Builder::ConvSpec ic; ic.name = "enc.ch_enc.0+bn+act"; ic.a = xin; ic.cm = ChanMap::identity(cfg.img_ch); ic.cin_true = cfg.img_ch; ic.kh = ic.kw = 5; ic.pad = 2;
+    ic.w = b.T("enc.ch_enc.0.weight", (int64_t)c0 * cfg.img_ch * 25); ic.bias = b.T("enc.ch_enc.0.bias", c0); ic.cout = c0; ic.Hout = ic.Wout = cfg.size_in;
+    ic.out_scale = &s0; ic.out_shift = &t0; ic.act = nvar ? ACT_LRELU01 : ACT_LRELU02;
+    View h = b.emit_conv(ic).out;
+    b.free_act(xin);
+    auto pool = [&](const View& in, int k, const std::string& name) {
+      if (in.H % k || in.W % k) throw std::runtime_error("plan: AvgPool2d does not divide the image");
+      View o = b.new_act(in.H / k, in.W / k, in.C);
+      Op& op = b.push(OP_AVGPOOL, name); op.bl.B = B; op.bl.scale = k; op.bl.in = in; op.bl.out = o;
+      b.free_act(in);
+      return o;
+    };
+    h = pool(h, 2, "enc.ch_enc.3 (AvgPool2d 2)");
+    for (int i = 0; i < cfg.n_enc; ++i) {
+      View o = emit_rblock(b, "enc.r_blocks." + std::to_string(i) + ".", h, 1, cfg.enc[i][0], cfg.enc[i][1], cfg.enc[i][2], nvar ? ACT_GELU : ACT_LRELU02);
+      b.free_act(h);
+      h = cfg.enc[i][3] > 1 ? pool(o, cfg.enc[i][3], "enc.r_blocks." + std::to_string(i) + ".down_pool") : o;
+    }
+    const int C = cfg.enc[cfg.n_enc - 1][2], half = C / 2, P = h.H * h.W, sz = cfg.size_z;
+    const float* wm = b.T("enc.mu_lin.weight", (int64_t)sz * half * P); const float* wl = b.T("enc.logvar_lin.weight", (int64_t)sz * half * P);
+    const float* bm = b.T("enc.mu_lin.bias", sz); const float* bl = b.T("enc.logvar_lin.bias", sz);
+    std::vector<float> w((size_t)2 * sz * C * P, 0.f), bias(2 * sz);
+    for (int n = 0; n < sz; ++n) {
+      for (int c = 0; c < half; ++c) for (int q = 0; q < P; ++q) {
+        w[((size_t)n * C + c) * P + q] = wm[((size_t)n * half + c) * P + q];
+        w[((size_t)(sz + n) * C + half + c) * P + q] = wl[((size_t)n * half + c) * P + q];
+      }
+      bias[n] = bm[n]; bias[sz + n] = bl[n];
+    }
+    Builder::ConvSpec fc; fc.name = "enc.mu_lin|enc.logvar_lin"; fc.a = h; fc.cm = ChanMap::identity(C); fc.cin_true = C; fc.kh = h.H; fc.kw = h.W; fc.pad = 0;
+    fc.w = w.data(); fc.bias = bias.data(); fc.cout = 2 * sz; fc.Hout = fc.Wout = 1; fc.out_nchw = true; fc.Hn = fc.Wn = 1;
+    b.emit_conv(fc);
+    b.free_act(h);
     finalize_gemm_tables(plan);
     return true;
   } catch (const std::exception& e) {

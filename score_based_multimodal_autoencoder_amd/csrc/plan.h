@@ -20,7 +20,7 @@
 
 namespace sbm {
 
-enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU02 = 2, ACT_RELU = 3, ACT_SIGMOID = 4, ACT_SILU = 5, ACT_SOFTPLUS = 6 };
+enum Act : int { ACT_NONE = 0, ACT_GELU = 1, ACT_LRELU02 = 2, ACT_RELU = 3, ACT_SIGMOID = 4, ACT_SILU = 5, ACT_SOFTPLUS = 6, ACT_LRELU01 = 7 };
 
 enum OpKind : int {
   OP_GEMM = 0,        // segmented implicit-GEMM convolution / linear (MFMA fp32)
@@ -34,6 +34,7 @@ enum OpKind : int {
   OP_GN_FINAL = 8,    // reduce GroupNorm partials to one partial (used when there are many)
   OP_GN32 = 9,        // GroupNorm(G, C) (+ SiLU) materialised: unet_openai normalization()
   OP_ATTN_QKV = 10,   // unet_openai QKVAttention core (softmax over T tokens, any head width)
+  OP_AVGPOOL = 12,    // AvgPool2d(k) PBC -> PBC (encoders); 11 is the profiling bucket of the chain kernel
 };
 
 // A view of an activation tensor inside the workspace arena.
@@ -197,6 +198,9 @@ struct ResDecCfg {
 };
 std::vector<TensorSpec> resdec_tensor_specs(const ResDecCfg& cfg);   // decoder-side entries only
 bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const* tensors, Plan* plan);
+// encoder side of the same modules (ResEncoder / ResEncoderN, h_vae_model_copy.py:41-71, 379-409): image -> [mu | logvar]
+std::vector<TensorSpec> resenc_tensor_specs(const ResDecCfg& cfg);
+bool build_resenc_plan(const ResDecCfg& cfg, int B, const float* const* tensors, Plan* plan);
 
 struct UnetOACfg {
   int in_channels = 3, model_channels = 128, out_channels = 3, num_res_blocks = 2;

@@ -3,8 +3,8 @@ ResVAE / ResAE (PolyMNIST, :91-174) and ResVAEN / ResAEN (CelebA, :457-588).
 
 Same constructors and `state_dict` keys.  `.decoder(z)` -- the only method on the sampling hot
 path -- runs as fused HIP kernels (BatchNorm folded into the convolutions, nearest upsampling folded
-into the consumer's reads).  `.encoder(x)` belongs to the conditional loop and is
-not built yet: it raises.
+into the consumer's reads).  `.encoder(x)` (the conditional loop's source of observed latents) runs the
+same way.
 """
 import torch
 
@@ -15,6 +15,7 @@ from ._module import ParamTreeModule, as_f32_cuda
 class _ResBase(ParamTreeModule):
     _variant_name = "ResVAE"
     _variant_id = 0
+    _returns_logvar = True
 
     def __init__(self, enc_channel_list, dec_channel_list, size_in=64, size_z=64, img_ch=3):
         super().__init__()
@@ -42,8 +43,25 @@ class _ResBase(ParamTreeModule):
         out = torch.empty((B, self.img_ch, self.size_in, self.size_in), device=z.device, dtype=torch.float32)
         return eng.forward(z, None, out)
 
+    def _encode(self, x):
+        """image (B, img_ch, size_in, size_in) -> (mu, logvar)   [ResEncoder.forward h_vae_model_copy.py:63-71, ResEncoderN :401-409]"""
+        x = as_f32_cuda(x, "encoder input")
+        if self.training:
+            raise RuntimeError("encoder runs with BatchNorm folded (eval mode); call .eval() first")
+        if x.dim() != 4 or tuple(x.shape[1:]) != (self.img_ch, self.size_in, self.size_in):
+            raise ValueError(f"expected (B, {self.img_ch}, {self.size_in}, {self.size_in}) images")
+        B = x.shape[0]
+        cfg = _lib.resdec_cfg_ints(self._variant_id, self.enc_channel_list, self.dec_channel_list, self.size_in,
+                                   self.size_z, self.img_ch)
+        eng = self._engine(("enc", B), lambda sd: _lib.Engine(_lib.SBM_RESENC, cfg, B, sd))
+        out = torch.empty((B, 2 * self.size_z), device=x.device, dtype=torch.float32)
+        eng.forward(x, None, out)
+        return out[:, :self.size_z], out[:, self.size_z:]
+
     def encoder(self, x):
-        raise NotImplementedError("encoder(x) is part of the conditional sampling loop (SURVEY.md 8(f1)); not built yet")
+        """VAE variants return (mu, logvar) (h_vae_model_copy.py:114-116, 480-482), AE variants mu (:162-164, 572-574)."""
+        mu, logvar = self._encode(x)
+        return (mu, logvar) if self._returns_logvar else mu.contiguous()
 
     def sample(self, amount, device):
         return self.decoder(torch.randn(amount, self.size_z).to(device))
@@ -55,6 +73,7 @@ class ResVAE(_ResBase):
 
 class ResAE(_ResBase):
     _variant_name, _variant_id = "ResAE", 0
+    _returns_logvar = False
 
 
 class ResVAEN(_ResBase):
@@ -63,3 +82,4 @@ class ResVAEN(_ResBase):
 
 class ResAEN(_ResBase):
     _variant_name, _variant_id = "ResAEN", 1
+    _returns_logvar = False

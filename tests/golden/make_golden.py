@@ -398,3 +398,22 @@ if __name__ == "__main__" and "alt" in sys.argv[1:]:
     alt_sampler_cases()
 if __name__ == "__main__" and "cond" in sys.argv[1:]:
     conditional_cases()
+
+
+def encoder_cases():
+    """CelebA-variant encoders (ResEncoderN + RBlockN: GELU, LeakyReLU(0.1)); the PolyMNIST ones are in decoders.npz."""
+    out = {}
+    for name, cls, enc, dec, ch in (("ResVAEN_img", ResVAEN, CEL_IMG_ENC, CEL_IMG_DEC, 3), ("ResAEN_mask", ResAEN, CEL_MASK_ENC, CEL_MASK_DEC, 1)):
+        m = cls(enc, dec, 128, 256, ch).eval()
+        synth.fill_module_(m)
+        x = inp(f"enc.{name}.x", (1, ch, 128, 128), 0.25) + 0.5
+        e = m.encoder(torch.from_numpy(x))
+        out[f"{name}_x"] = x
+        out[f"{name}_mu"] = (e[0] if isinstance(e, tuple) else e).numpy()
+        if isinstance(e, tuple):
+            out[f"{name}_logvar"] = e[1].numpy()
+    save("encoders.npz", **out)
+
+
+if __name__ == "__main__" and "enc" in sys.argv[1:]:
+    encoder_cases()

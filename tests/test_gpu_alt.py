@@ -88,12 +88,10 @@ def test_mlp_langevin_matches_calc_poly_uncond(pkg, golden, sched):
 @pytest.mark.parametrize("tag,n_mod,pred", [("genae_cond", 2, (1,)), ("genae_all2", 2, (0, 1)), ("genae_all10", 10, tuple(range(10)))])
 def test_annealed_langevin_matches_gen_ae(pkg, golden, tag, n_mod, pred):
     """The full 200-level chain of fid_upd10.gen_ae (4000 / 400 score calls), intermediate states and decoded outputs."""
-    from oracle import decoders as OD                       # checker only: the observed latents come from the oracle encoder
     g = golden("alt_samplers.npz")
     arch, synth = pkg["arch"], pkg["synth"]
     unet = _filled(pkg, pkg["unet"].Unet(channels=n_mod, **TINY))
     ae = _filled(pkg, pkg["vae"].ResAE(arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3))
-    esd = synth.fill_state_dict(arch.resvae_state_shapes("ResAE", arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3))
     seed, B = int(g[f"{tag}_seed"][0]), 2
     k = 0
     z0 = np.zeros((B, n_mod, 64), np.float32)
@@ -102,7 +100,7 @@ def test_annealed_langevin_matches_gen_ae(pkg, golden, tag, n_mod, pred):
             z0[:, m] = synth.noise(seed, k, (B, 64))
             k += 1
         else:
-            z0[:, m] = OD.res_encoder(esd, g[f"{tag}_p"][m], arch.POLY_ENC, "ResAE")[0]
+            z0[:, m] = ae.encoder(dev(g[f"{tag}_p"][m])).cpu().numpy()          # fid_upd10.py:83: observed latents from the encoder
     iters = 2 if len(pred) == 10 else 20
     steps = 200 * iters
     noise = np.zeros((steps, B, n_mod, 64), np.float32)
@@ -147,12 +145,10 @@ def test_annealed_langevin_per_modality_coefficients_and_philox(pkg):
 
 @pytest.mark.parametrize("tag,noise_obs,pc", [("nobs1_pc1", True, True), ("nobs0_pc0", False, False)])
 def test_conditional_loop_matches_evaluate(pkg, golden, tag, noise_obs, pc):
-    from oracle import decoders as OD                       # checker only (encoder for the observed modality)
     g = golden("conditional.npz")
     arch, synth, S = pkg["arch"], pkg["synth"], pkg["sde"]
     unet = _filled(pkg, pkg["unet"].Unet(channels=2, **TINY))
     ae = _filled(pkg, pkg["vae"].ResAE(arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3))
-    esd = synth.fill_state_dict(arch.resvae_state_shapes("ResAE", arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3))
     sde = S.VPSDE(0.1, 5.0, 20)
 
     def image(state):
@@ -161,12 +157,12 @@ def test_conditional_loop_matches_evaluate(pkg, golden, tag, noise_obs, pc):
 
     xm = S.uncond_sampler((1, 2, 8, 8), unet, "cuda", sde, pc=pc, order="pc", x0=dev(g[f"{tag}_unc_prior"]), noise=dev(g[f"{tag}_unc_noise"]))
     assert_close(image(xm), g[f"{tag}_unc_img"], 5e-4, 5e-4, "unconditional image")
-    z_obs = np.zeros((1, 2, 8, 8), np.float32)
-    z_obs[0, 0] = OD.res_encoder(esd, g[f"{tag}_imgs"][0], arch.POLY_ENC, "ResAE")[0][0].reshape(8, 8)
-    x0 = np.zeros_like(z_obs)
+    z_obs = torch.zeros(1, 2, 8, 8, device="cuda")
+    z_obs[0, 0] = ae.encoder(dev(g[f"{tag}_imgs"][0]))[0].reshape(8, 8)          # given = first modality, first sample
+    x0 = np.zeros((1, 2, 8, 8), np.float32)
     x0[0, 1] = g[f"{tag}_cond_z0"].reshape(8, 8)
-    out = S.cond_sampler(dev(z_obs), [0], unet, sde, pc=pc, noise_obs=noise_obs, x0=dev(x0), noise=dev(g[f"{tag}_cond_noise"]))
-    assert torch.equal(out[:, 0], dev(z_obs)[:, 0])
+    out = S.cond_sampler(z_obs, [0], unet, sde, pc=pc, noise_obs=noise_obs, x0=dev(x0), noise=dev(g[f"{tag}_cond_noise"]))
+    assert torch.equal(out[:, 0], z_obs[:, 0])
     assert_close(image(out), g[f"{tag}_cond_img"], 5e-4, 5e-4, "conditional image")
 
 

@@ -387,3 +387,37 @@ def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
     scale = float(outs["0"].abs().max())
     assert float((outs["0"] - outs["16"]).abs().max()) <= 2e-5 * scale
     assert torch.isfinite(outs["16"]).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# encoders (the conditional loop's source of observed latents)
+@pytest.mark.parametrize("name", ["ResVAE", "ResAE"])
+def test_poly_encoders(pkg, golden, name):
+    g = golden("decoders.npz")
+    arch = pkg["arch"]
+    m = getattr(pkg["vae"], name)(arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3).eval()
+    pkg["synth"].fill_module_(m)
+    m = m.cuda()
+    e = m.encoder(dev(g[f"{name}_encx"]))
+    mu = (e[0] if isinstance(e, tuple) else e).cpu().numpy()
+    assert isinstance(e, tuple) == (name == "ResVAE")          # VAE: (mu, logvar); AE: mu  (h_vae_model_copy.py:114-116, 162-164)
+    assert_close(mu, g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
+    if name == "ResVAE":
+        assert_close(e[1].cpu().numpy(), g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")
+    with pytest.raises(ValueError):
+        m.encoder(torch.zeros(2, 3, 16, 16, device="cuda"))
+
+
+@pytest.mark.parametrize("name,cls,enc,dec,ch", [("ResVAEN_img", "ResVAEN", "CEL_IMG_ENC", "CEL_IMG_DEC", 3),
+                                                 ("ResAEN_mask", "ResAEN", "CEL_MASK_ENC", "CEL_MASK_DEC", 1)])
+def test_celeba_encoders(pkg, golden, name, cls, enc, dec, ch):
+    g = golden("encoders.npz")
+    arch = pkg["arch"]
+    m = getattr(pkg["vae"], cls)(getattr(arch, enc), getattr(arch, dec), 128, 256, ch).eval()
+    pkg["synth"].fill_module_(m)
+    m = m.cuda()
+    e = m.encoder(dev(g[f"{name}_x"]))
+    mu = (e[0] if isinstance(e, tuple) else e).cpu().numpy()
+    assert_close(mu, g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
+    if isinstance(e, tuple):
+        assert_close(e[1].cpu().numpy(), g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")

@@ -146,3 +146,14 @@ def test_attr_decoder(golden, name):
     sd = synth.fill_state_dict(arch.attr_state_shapes(256, ae=(name == "AttrBNAE")))
     y = OD.attr_decoder(sd, g[f"{name}_z"])
     assert_close(y, g[f"{name}_y"], 1e-5, 1e-5 * np.abs(g[f"{name}_y"]).max(), name)
+
+
+@pytest.mark.parametrize("name,variant,enc,ch", [("ResVAEN_img", "ResVAEN", "CEL_IMG_ENC", 3), ("ResAEN_mask", "ResAEN", "CEL_MASK_ENC", 1)])
+def test_celeba_encoders(golden, name, variant, enc, ch):
+    g = golden("encoders.npz")
+    dec = {"CEL_IMG_ENC": "CEL_IMG_DEC", "CEL_MASK_ENC": "CEL_MASK_DEC"}[enc]
+    sd = synth.fill_state_dict(arch.resvae_state_shapes(variant, getattr(arch, enc), getattr(arch, dec), 128, 256, ch))
+    mu, lv = OD.res_encoder(sd, g[f"{name}_x"], getattr(arch, enc), variant)
+    assert_close(mu, g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
+    if f"{name}_logvar" in g:
+        assert_close(lv, g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")

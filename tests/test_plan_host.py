@@ -138,3 +138,25 @@ def test_mlp_score_plan(golden, tag, n_mod, size_z):
     plan = planref.RefPlan(4, [n_mod, size_z], x.shape[0], sd)
     y = plan.run(x, None, x.shape)
     assert_close(y, g[f"{tag}_y"], 1e-5, 1e-5 * np.abs(g[f"{tag}_y"]).max(), tag)
+
+
+@pytest.mark.parametrize("name", ["ResVAE", "ResAE"])
+def test_poly_encoder_plan(golden, name):
+    """ResEncoder as a plan (conv5x5+BN, AvgPool ops, RBlocks, mu|logvar as one full-image conv) on the host interpreter."""
+    g = golden("decoders.npz")
+    sd = synth.fill_state_dict(arch.resvae_state_shapes(name, arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3))
+    x = g[f"{name}_encx"]
+    plan = planref.RefPlan(5, planref.resdec_cfg_ints(0, arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3), x.shape[0], sd)
+    y = plan.run(x, None, (x.shape[0], 128))
+    assert_close(y[:, :64], g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
+    if name == "ResVAE":
+        assert_close(y[:, 64:], g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")
+
+
+def test_celeba_mask_encoder_plan(golden):
+    g = golden("encoders.npz")
+    sd = synth.fill_state_dict(arch.resvae_state_shapes("ResAEN", arch.CEL_MASK_ENC, arch.CEL_MASK_DEC, 128, 256, 1))
+    x = g["ResAEN_mask_x"]
+    plan = planref.RefPlan(5, planref.resdec_cfg_ints(1, arch.CEL_MASK_ENC, arch.CEL_MASK_DEC, 128, 256, 1), 1, sd)
+    y = plan.run(x, None, (1, 512))
+    assert_close(y[:, :256], g["ResAEN_mask_mu"], 1e-5, 1e-5 * np.abs(g["ResAEN_mask_mu"]).max(), "ResAEN mask mu")
