@@ -33,7 +33,9 @@ enum sbm_kind {
   SBM_UNET_OA = 3, /* unet_openai.UNetModel (conditional CelebA score net)   unet_openai.py:361-575 */
   SBM_MLP = 4,     /* lat_sm2_model.LSMPoly64_sm (MLP score, DSM Langevin)   lat_sm2_model.py:348-371; cfg [n_mod, size_z] */
   SBM_RESENC = 5   /* h_vae_model_copy.ResVAE/ResAE/ResVAEN/ResAEN.encoder: image (B,img_ch,s,s) -> (B, 2*size_z) = [mu | logvar]
-                      h_vae_model_copy.py:41-71,379-409; cfg as SBM_RESDEC */
+                      h_vae_model_copy.py:41-71,379-409; cfg as SBM_RESDEC */,
+  SBM_ATTRENC = 6  /* h_vae_model.CelebAAttrNewBN[AE].encoder: attributes (B, att_size) -> (B, 2*size_z) = [mu | logvar] (AE: (B, size_z))
+                      h_vae_model.py:718-736,756-759, 845-863,884-887; cfg [size_z, att_size, ae] */
 };
 
 /* Integer configuration vectors (`cfg`):

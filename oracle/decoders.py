@@ -56,6 +56,17 @@ def attr_decoder(sd, z):
     return O.linear(h, sd["dec_net.15.weight"], sd["dec_net.15.bias"])
 
 
+def attr_encoder(sd, x):
+    """CelebAAttrNewBN[AE].encoder h_vae_model.py:718-736,756-759 / :845-863,884-887: 5x(Linear,BN1d,ReLU) + mu_lin (+ logvar_lin)."""
+    h = np.asarray(x, F32)
+    for i in range(5):
+        h = O.linear(h, sd[f"enc_net.{3 * i}.weight"], sd[f"enc_net.{3 * i}.bias"])
+        h = O.relu(_bn(sd, f"enc_net.{3 * i + 1}.", h))
+    mu = O.linear(h, sd["mu_lin.weight"], sd["mu_lin.bias"])
+    lv = O.linear(h, sd["logvar_lin.weight"], sd["logvar_lin.bias"]) if "logvar_lin.weight" in sd else None
+    return mu, lv
+
+
 def res_encoder(sd, x, enc_channel_list, variant="ResVAE"):
     """ResEncoder.forward h_vae_model_copy.py:63-71 / ResEncoderN :401-409.  Returns (mu, logvar)."""
     new = variant in ("ResVAEN", "ResAEN")

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(CSRC, "libsbmae_hip.so")
 SOURCES = ["plan.cpp", "kernels.hip", "chain.hip", "sampler.hip", "api.hip"]
 HEADERS = ["plan.h", "device.h", os.path.join("..", "..", "include", "sbmae.h")]
 
-SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA, SBM_MLP, SBM_RESENC = 0, 1, 2, 3, 4, 5
+SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA, SBM_MLP, SBM_RESENC, SBM_ATTRENC = 0, 1, 2, 3, 4, 5, 6
 OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "nchw_to_pbc", "bilinear", "gn_final", "gn32",
                  "attn_qkv", "chain_kernel", "avgpool"]
 

@@ -67,6 +67,7 @@ static std::vector<TensorSpec> specs_of(int kind, const int* cfg) {
   if (kind == SBM_UNET_OA) return unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg));
   if (kind == SBM_MLP) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; return mlp_tensor_specs(c); }
   if (kind == SBM_RESENC) return resenc_tensor_specs(resdec_cfg_from_ints(cfg));
+  if (kind == SBM_ATTRENC) { AttrEncCfg c; c.size_z = cfg[0]; c.att_size = cfg[1]; c.ae = cfg[2]; return attrenc_tensor_specs(c); }
   if (kind == SBM_UNET) return unet_tensor_specs(unet_cfg_from_ints(cfg));
   if (kind == SBM_RESDEC) return resdec_tensor_specs(resdec_cfg_from_ints(cfg));
   if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; return attrdec_tensor_specs(a); }
@@ -134,6 +135,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   else if (kind == SBM_UNET_OA) ok = build_unet_oa_plan(unet_oa_cfg_from_ints(cfg), batch, in_pitch, host_tensors, &m->plan);
   else if (kind == SBM_MLP) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; ok = build_mlp_plan(c, batch, host_tensors, &m->plan); }
   else if (kind == SBM_RESENC) ok = build_resenc_plan(resdec_cfg_from_ints(cfg), batch, host_tensors, &m->plan);
+  else if (kind == SBM_ATTRENC) { AttrEncCfg c; c.size_z = cfg[0]; c.att_size = cfg[1]; c.ae = cfg[2]; ok = build_attrenc_plan(c, batch, host_tensors, &m->plan); }
   else m->plan.error = "unknown model kind";
   if (!ok) { std::string e = m->plan.error; delete m; return fail("sbm_model_create: " + e); }
   const size_t pbytes = m->plan.params.size() * sizeof(float), wbytes = (size_t)m->plan.ws_floats * sizeof(float);

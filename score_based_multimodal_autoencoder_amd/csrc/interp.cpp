@@ -324,6 +324,7 @@ void* sbmref_build(int kind, const int* cfg, int B, int z_ld, const float* const
   else if (kind == 3) ok = build_unet_oa_plan(unet_oa_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);
   else if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; ok = build_mlp_plan(c, B, tensors, &h->plan); }
   else if (kind == 5) ok = build_resenc_plan(resdec_cfg_from_ints(cfg), B, tensors, &h->plan);
+  else if (kind == 6) { AttrEncCfg c; c.size_z = cfg[0]; c.att_size = cfg[1]; c.ae = cfg[2]; ok = build_attrenc_plan(c, B, tensors, &h->plan); }
   if (!ok) { g_err = h->plan.error.empty() ? "unknown plan kind" : h->plan.error; delete h; return nullptr; }
   h->ws.assign((size_t)h->plan.ws_floats, std::nanf(""));      // poison: every read must be preceded by a write
   return h;
@@ -335,6 +336,7 @@ int sbmref_num_specs(int kind, const int* cfg) {
   if (kind == 3) return (int)unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg)).size();
   if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; return (int)mlp_tensor_specs(c).size(); }
   if (kind == 5) return (int)resenc_tensor_specs(resdec_cfg_from_ints(cfg)).size();
+  if (kind == 6) { AttrEncCfg c; c.size_z = cfg[0]; c.att_size = cfg[1]; c.ae = cfg[2]; return (int)attrenc_tensor_specs(c).size(); }
   AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1];
   return (int)attrdec_tensor_specs(a).size();
 }
@@ -346,6 +348,7 @@ long sbmref_spec(int kind, const int* cfg, int i, char* name, int cap) {
   else if (kind == 3) s = unet_oa_tensor_specs(unet_oa_cfg_from_ints(cfg));
   else if (kind == 4) { MlpCfg c; c.n_mod = cfg[0]; c.size_z = cfg[1]; s = mlp_tensor_specs(c); }
   else if (kind == 5) s = resenc_tensor_specs(resdec_cfg_from_ints(cfg));
+  else if (kind == 6) { AttrEncCfg c; c.size_z = cfg[0]; c.att_size = cfg[1]; c.ae = cfg[2]; s = attrenc_tensor_specs(c); }
   else { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; s = attrdec_tensor_specs(a); }
   if (i < 0 || i >= (int)s.size()) return -1;
   std::strncpy(name, s[i].name.c_str(), cap - 1); name[cap - 1] = 0;

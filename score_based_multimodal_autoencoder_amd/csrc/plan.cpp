@@ -141,6 +141,23 @@ std::vector<TensorSpec> resenc_tensor_specs(const ResDecCfg& c) {
 
 static const int kAttrW[5] = {512, 512, 512, 256, 128};
 
+static const int kAttrEncW[5] = {128, 256, 512, 512, 512};
+
+std::vector<TensorSpec> attrenc_tensor_specs(const AttrEncCfg& c) {
+  SpecList L;
+  int prev = c.att_size;
+  for (int i = 0; i < 5; ++i) {
+    std::string l = "enc_net." + std::to_string(3 * i) + ".", b = "enc_net." + std::to_string(3 * i + 1) + ".";
+    L.add(l + "weight", {kAttrEncW[i], prev}); L.add(l + "bias", {kAttrEncW[i]});
+    L.add(b + "weight", {kAttrEncW[i]}); L.add(b + "bias", {kAttrEncW[i]});
+    L.add(b + "running_mean", {kAttrEncW[i]}); L.add(b + "running_var", {kAttrEncW[i]});
+    prev = kAttrEncW[i];
+  }
+  L.add("mu_lin.weight", {c.size_z, prev}); L.add("mu_lin.bias", {c.size_z});
+  if (!c.ae) { L.add("logvar_lin.weight", {c.size_z, prev}); L.add("logvar_lin.bias", {c.size_z}); }
+  return L.v;
+}
+
 std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& c) {
   SpecList L;
   int prev = c.size_z;
@@ -1314,6 +1331,46 @@ bool build_attrdec_plan(const AttrDecCfg& cfg, int B, int z_ld, const float* con
     Builder::ConvSpec c; c.name = "dec_net.15"; c.a = h; c.cm = ChanMap::identity(prev); c.cin_true = prev;
     c.w = b.T("dec_net.15.weight", (int64_t)cfg.att_size * prev); c.bias = b.T("dec_net.15.bias", cfg.att_size); c.cout = cfg.att_size;
     c.out_nchw = true; c.Hn = c.Wn = 1;
+    b.emit_conv(c);
+    b.free_act(h);
+    finalize_gemm_tables(plan);
+    return true;
+  } catch (const std::exception& e) {
+    plan->error = e.what();
+    return false;
+  }
+}
+
+bool build_attrenc_plan(const AttrEncCfg& cfg, int B, const float* const* tensors, Plan* plan) {
+  try {
+    std::vector<TensorSpec> specs = attrenc_tensor_specs(cfg);
+    Builder b(plan, B, specs, tensors);
+    const int nout = cfg.ae ? cfg.size_z : 2 * cfg.size_z;
+    plan->in_C = cfg.att_size; plan->in_H = plan->in_W = 1; plan->in_ld = 0;
+    plan->out_C = nout; plan->out_H = plan->out_W = 1;
+    View h = b.new_act(1, 1, cfg.att_size);
+    { Op& op = b.push(OP_NCHW_TO_PBC, "input"); op.cv.B = B; op.cv.C = cfg.att_size; op.cv.Hn = 1; op.cv.Wn = 1; op.cv.out = h; }
+    int prev = cfg.att_size;
+    for (int i = 0; i < 5; ++i) {
+      std::string l = "enc_net." + std::to_string(3 * i) + ".", bnp = "enc_net." + std::to_string(3 * i + 1) + ".";
+      std::vector<double> s, t;
+      bn_fold(b, bnp, kAttrEncW[i], &s, &t);
+      Builder::ConvSpec c; c.name = l + "+bn+relu"; c.a = h; c.cm = ChanMap::identity(prev); c.cin_true = prev;
+      c.w = b.T(l + "weight", (int64_t)kAttrEncW[i] * prev); c.bias = b.T(l + "bias", kAttrEncW[i]); c.cout = kAttrEncW[i];
+      c.out_scale = &s; c.out_shift = &t; c.act = ACT_RELU;
+      View o = b.emit_conv(c).out;
+      b.free_act(h);
+      h = o; prev = kAttrEncW[i];
+    }
+    std::vector<float> w((size_t)nout * prev), bias(nout);
+    std::memcpy(w.data(), b.T("mu_lin.weight", (int64_t)cfg.size_z * prev), sizeof(float) * cfg.size_z * prev);
+    std::memcpy(bias.data(), b.T("mu_lin.bias", cfg.size_z), sizeof(float) * cfg.size_z);
+    if (!cfg.ae) {
+      std::memcpy(w.data() + (size_t)cfg.size_z * prev, b.T("logvar_lin.weight", (int64_t)cfg.size_z * prev), sizeof(float) * cfg.size_z * prev);
+      std::memcpy(bias.data() + cfg.size_z, b.T("logvar_lin.bias", cfg.size_z), sizeof(float) * cfg.size_z);
+    }
+    Builder::ConvSpec c; c.name = cfg.ae ? "mu_lin" : "mu_lin|logvar_lin"; c.a = h; c.cm = ChanMap::identity(prev); c.cin_true = prev;
+    c.w = w.data(); c.bias = bias.data(); c.cout = nout; c.out_nchw = true; c.Hn = c.Wn = 1;
     b.emit_conv(c);
     b.free_act(h);
     finalize_gemm_tables(plan);

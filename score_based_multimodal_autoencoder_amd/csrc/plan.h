@@ -218,6 +218,11 @@ struct MlpCfg { int n_mod = 5, size_z = 64; };
 std::vector<TensorSpec> mlp_tensor_specs(const MlpCfg& cfg);
 bool build_mlp_plan(const MlpCfg& cfg, int B, const float* const* tensors, Plan* plan);
 
+// CelebAAttrNewBN[AE].encoder (h_vae_model.py:718-736, 756-759; AE :845-863, 884-887): attributes (B, att_size) -> [mu | logvar]
+struct AttrEncCfg { int size_z = 64, att_size = 18, ae = 0; };
+std::vector<TensorSpec> attrenc_tensor_specs(const AttrEncCfg& cfg);
+bool build_attrenc_plan(const AttrEncCfg& cfg, int B, const float* const* tensors, Plan* plan);
+
 struct AttrDecCfg { int size_z = 256, att_size = 18; };
 std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& cfg);
 bool build_attrdec_plan(const AttrDecCfg& cfg, int B, int z_ld, const float* const* tensors, Plan* plan);

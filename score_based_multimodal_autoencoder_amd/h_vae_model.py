@@ -4,7 +4,7 @@ BatchNorm1d, ReLU) + Linear -> 18 logits, as HIP GEMMs with the BatchNorm folded
 import torch
 
 from . import _lib, arch
-from ._module import ParamTreeModule
+from ._module import ParamTreeModule, as_f32_cuda
 
 
 class CelebAAttrNewBN(ParamTreeModule):
@@ -30,7 +30,18 @@ class CelebAAttrNewBN(ParamTreeModule):
         return eng.forward(z, None, out)
 
     def encoder(self, x):
-        raise NotImplementedError("encoder(x) is part of the conditional sampling loop (SURVEY.md 8(f1)); not built yet")
+        """attributes (B, att_size) -> (mu, logvar)  [h_vae_model.py:756-759]; the AE class returns mu  [:884-887]"""
+        x = as_f32_cuda(x, "encoder input")
+        if self.training:
+            raise RuntimeError("encoder runs with BatchNorm folded (eval mode); call .eval() first")
+        if x.dim() != 2 or x.shape[1] != self.att_size:
+            raise ValueError(f"expected (B, {self.att_size}) attribute vectors")
+        B = x.shape[0]
+        eng = self._engine(("enc", B), lambda sd: _lib.Engine(_lib.SBM_ATTRENC, [self.size_z, self.att_size, int(self._ae)], B, sd))
+        nout = self.size_z if self._ae else 2 * self.size_z
+        out = torch.empty((B, nout), device=x.device, dtype=torch.float32)
+        eng.forward(x, None, out)
+        return out if self._ae else (out[:, :self.size_z], out[:, self.size_z:])
 
 
 class CelebAAttrNewBNAE(CelebAAttrNewBN):

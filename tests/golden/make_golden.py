@@ -412,6 +412,15 @@ def encoder_cases():
         out[f"{name}_mu"] = (e[0] if isinstance(e, tuple) else e).numpy()
         if isinstance(e, tuple):
             out[f"{name}_logvar"] = e[1].numpy()
+    for name, cls in (("AttrBN", CelebAAttrNewBN), ("AttrBNAE", CelebAAttrNewBNAE)):
+        m = cls(256).eval()
+        synth.fill_module_(m)
+        x = (inp(f"enc.{name}.x", (5, 18)) > 0).astype(np.float32)          # 0/1 attribute vectors
+        e = m.encoder(torch.from_numpy(x))
+        out[f"{name}_x"] = x
+        out[f"{name}_mu"] = (e[0] if isinstance(e, tuple) else e).numpy()
+        if isinstance(e, tuple):
+            out[f"{name}_logvar"] = e[1].numpy()
     save("encoders.npz", **out)
 
 

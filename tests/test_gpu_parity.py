@@ -421,3 +421,18 @@ def test_celeba_encoders(pkg, golden, name, cls, enc, dec, ch):
     assert_close(mu, g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
     if isinstance(e, tuple):
         assert_close(e[1].cpu().numpy(), g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")
+
+
+@pytest.mark.parametrize("name", ["AttrBN", "AttrBNAE"])
+def test_attr_encoders(pkg, golden, name):
+    g = golden("encoders.npz")
+    cls = pkg["attr"].CelebAAttrNewBN if name == "AttrBN" else pkg["attr"].CelebAAttrNewBNAE
+    m = cls(256).eval()
+    pkg["synth"].fill_module_(m)
+    m = m.cuda()
+    e = m.encoder(dev(g[f"{name}_x"]))
+    mu = (e[0] if isinstance(e, tuple) else e).cpu().numpy()
+    assert isinstance(e, tuple) == (name == "AttrBN")
+    assert_close(mu, g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
+    if isinstance(e, tuple):
+        assert_close(e[1].cpu().numpy(), g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")

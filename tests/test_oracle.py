@@ -157,3 +157,13 @@ def test_celeba_encoders(golden, name, variant, enc, ch):
     assert_close(mu, g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
     if f"{name}_logvar" in g:
         assert_close(lv, g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")
+
+
+@pytest.mark.parametrize("name,ae", [("AttrBN", False), ("AttrBNAE", True)])
+def test_attr_encoders(golden, name, ae):
+    g = golden("encoders.npz")
+    sd = synth.fill_state_dict(arch.attr_state_shapes(256, 18, ae))
+    mu, lv = OD.attr_encoder(sd, g[f"{name}_x"])
+    assert_close(mu, g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
+    if not ae:
+        assert_close(lv, g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")

@@ -160,3 +160,15 @@ def test_celeba_mask_encoder_plan(golden):
     plan = planref.RefPlan(5, planref.resdec_cfg_ints(1, arch.CEL_MASK_ENC, arch.CEL_MASK_DEC, 128, 256, 1), 1, sd)
     y = plan.run(x, None, (1, 512))
     assert_close(y[:, :256], g["ResAEN_mask_mu"], 1e-5, 1e-5 * np.abs(g["ResAEN_mask_mu"]).max(), "ResAEN mask mu")
+
+
+@pytest.mark.parametrize("name,ae", [("AttrBN", 0), ("AttrBNAE", 1)])
+def test_attr_encoder_plan(golden, name, ae):
+    g = golden("encoders.npz")
+    sd = synth.fill_state_dict(arch.attr_state_shapes(256, 18, bool(ae)))
+    x = g[f"{name}_x"]
+    plan = planref.RefPlan(6, [256, 18, ae], x.shape[0], sd)
+    y = plan.run(x.reshape(x.shape[0], 18, 1, 1), None, (x.shape[0], 256 if ae else 512))
+    assert_close(y[:, :256], g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
+    if not ae:
+        assert_close(y[:, 256:], g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")
