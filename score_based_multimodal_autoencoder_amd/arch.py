@@ -305,3 +305,50 @@ def mlp_entries(n_mod=5, size_z=128):
 
 def mlp_state_shapes(n_mod=5, size_z=128):
     return dict(mlp_entries(n_mod, size_z))
+
+
+def _proj_head(d):
+    yield "proj.projection.weight", (d, d)
+    yield "proj.projection.bias", (d,)
+    yield "proj.fc.weight", (d, d)
+    yield "proj.fc.bias", (d,)
+    yield "proj.layer_norm.weight", (d,)
+    yield "proj.layer_norm.bias", (d,)
+
+
+CEL_IMG_REP_ENC = [(64, 128, 128, 2), (128, 256, 256, 2), (256, 512, 512, 2)]
+CEL_MASK_REP_ENC = [(64, 128, 128, 4), (128, 256, 256, 4)]
+
+
+def cel_rep_entries(enc_channel_list, size_z=512, img_ch=3, size_in=128):
+    """CelImgRep / CelMaskRep state_dict (h_vae_model.py:1040-1072): ResEncoderN under `enc.` + ProjectionHead under `proj.`."""
+    half = size_in // 2
+    for c in enc_channel_list:
+        half //= c[3]
+    lin = half * half * (enc_channel_list[-1][2] // 2)
+    c0 = enc_channel_list[0][0]
+    yield "enc.ch_enc.0.weight", (c0, img_ch, 5, 5)
+    yield "enc.ch_enc.0.bias", (c0,)
+    yield from _bn("enc.ch_enc.1.", c0)
+    for i, (ci, cm, co, _r) in enumerate(enc_channel_list):
+        yield from _rblock(f"enc.r_blocks.{i}.", ci, cm, co)
+    yield "enc.mu_lin.weight", (size_z, lin)
+    yield "enc.mu_lin.bias", (size_z,)
+    yield "enc.logvar_lin.weight", (size_z, lin)
+    yield "enc.logvar_lin.bias", (size_z,)
+    yield from _proj_head(size_z)
+
+
+def cel_attr_rep_entries(att_size=18, size_z=512):
+    """CelAttrRep state_dict (h_vae_model.py:987-1002): CelAttrEnc under `enc.` + ProjectionHead under `proj.`."""
+    prev = att_size
+    for i, w in enumerate(ATTR_ENC_WIDTHS):
+        yield f"enc.enc_net.{3 * i}.weight", (w, prev)
+        yield f"enc.enc_net.{3 * i}.bias", (w,)
+        yield from _bn(f"enc.enc_net.{3 * i + 1}.", w)
+        prev = w
+    yield "enc.mu_lin.weight", (size_z, prev)
+    yield "enc.mu_lin.bias", (size_z,)
+    yield "enc.logvar_lin.weight", (size_z, prev)
+    yield "enc.logvar_lin.bias", (size_z,)
+    yield from _proj_head(size_z)

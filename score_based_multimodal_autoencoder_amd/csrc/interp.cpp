@@ -171,14 +171,14 @@ static void run_attn(const AttnOp& a, bool linear, float* ws) {
   }
 }
 
-static void run_gn_res(const GnResOp& g, const float* prm, float* ws) {
+static void run_gn_res(const GnResOp& g, const float* prm, float* ws, float* ext_out) {
   const int B = g.B, P = g.u.H * g.u.W, C = g.u.C;
   for (int b = 0; b < B; ++b) {
     float mean, rstd; gn_mean_rstd(ws, g.part_off, g.nparts, B, b, g.inv_count, &mean, &rstd);
     for (int p = 0; p < P; ++p) for (int c = 0; c < C; ++c) {
       float u = ws[g.u.off + ((int64_t)p * B + b) * g.u.ld + c];
       float y = ((u - mean) * rstd) * prm[g.gamma_off + c] + prm[g.beta_off + c];
-      ws[g.out.off + ((int64_t)p * B + b) * g.out.ld + c] = y + ws[g.x.off + ((int64_t)p * B + b) * g.x.ld + c];
+      (g.out_ext ? ext_out : ws + g.out.off)[((int64_t)p * B + b) * g.out.ld + c] = y + ws[g.x.off + ((int64_t)p * B + b) * g.x.ld + c];
     }
   }
 }
@@ -210,7 +210,7 @@ void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const 
       case OP_DWCONV7: run_dw(op.dw, prm, ws.data()); break;
       case OP_LINATTN: run_attn(op.at, true, ws.data()); break;
       case OP_ATTN: run_attn(op.at, false, ws.data()); break;
-      case OP_GN_RES: run_gn_res(op.gr, prm, ws.data()); break;
+      case OP_GN_RES: run_gn_res(op.gr, prm, ws.data(), out); break;
       case OP_SINUS: {
         const SinusOp& s = op.si; const int half = s.dim / 2;
         for (int b = 0; b < s.B; ++b) for (int j = 0; j < half; ++j) {

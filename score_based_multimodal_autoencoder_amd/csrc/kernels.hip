@@ -1029,7 +1029,8 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       else SBM_KLAUNCH(attn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
     } break;
     case OP_GN_RES: {
-      const GnResOp& o = op.gr; const GnResArgs g = make_gnres_args(o, prm, ws);
+      const GnResOp& o = op.gr; GnResArgs g = make_gnres_args(o, prm, ws);
+      if (o.out_ext) g.out = ext_out;
       SBM_KLAUNCH(gn_res_kernel, dim3(o.B), dim3(256), 0, st, g);
     } break;
     case OP_SINUS: {

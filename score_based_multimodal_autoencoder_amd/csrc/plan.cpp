@@ -125,6 +125,12 @@ std::vector<TensorSpec> resdec_tensor_specs(const ResDecCfg& c) {
   return L.v;
 }
 
+static void spec_proj_head(SpecList& L, int d) {
+  L.add("proj.projection.weight", {d, d}); L.add("proj.projection.bias", {d});
+  L.add("proj.fc.weight", {d, d}); L.add("proj.fc.bias", {d});
+  L.add("proj.layer_norm.weight", {d}); L.add("proj.layer_norm.bias", {d});
+}
+
 std::vector<TensorSpec> resenc_tensor_specs(const ResDecCfg& c) {
   SpecList L;
   const int c0 = c.enc[0][0];
@@ -135,7 +141,8 @@ std::vector<TensorSpec> resenc_tensor_specs(const ResDecCfg& c) {
   for (int i = 0; i < c.n_enc; ++i) s /= c.enc[i][3];
   const int64_t lin = (int64_t)s * s * (c.enc[c.n_enc - 1][2] / 2);
   L.add("enc.mu_lin.weight", {c.size_z, lin}); L.add("enc.mu_lin.bias", {c.size_z});
-  L.add("enc.logvar_lin.weight", {c.size_z, lin}); L.add("enc.logvar_lin.bias", {c.size_z});
+  if (c.variant & 2) spec_proj_head(L, c.size_z);
+  else { L.add("enc.logvar_lin.weight", {c.size_z, lin}); L.add("enc.logvar_lin.bias", {c.size_z}); }
   return L.v;
 }
 
@@ -146,15 +153,17 @@ static const int kAttrEncW[5] = {128, 256, 512, 512, 512};
 std::vector<TensorSpec> attrenc_tensor_specs(const AttrEncCfg& c) {
   SpecList L;
   int prev = c.att_size;
+  const std::string pre = c.ae == 2 ? "enc." : "";
   for (int i = 0; i < 5; ++i) {
-    std::string l = "enc_net." + std::to_string(3 * i) + ".", b = "enc_net." + std::to_string(3 * i + 1) + ".";
+    std::string l = pre + "enc_net." + std::to_string(3 * i) + ".", b = pre + "enc_net." + std::to_string(3 * i + 1) + ".";
     L.add(l + "weight", {kAttrEncW[i], prev}); L.add(l + "bias", {kAttrEncW[i]});
     L.add(b + "weight", {kAttrEncW[i]}); L.add(b + "bias", {kAttrEncW[i]});
     L.add(b + "running_mean", {kAttrEncW[i]}); L.add(b + "running_var", {kAttrEncW[i]});
     prev = kAttrEncW[i];
   }
-  L.add("mu_lin.weight", {c.size_z, prev}); L.add("mu_lin.bias", {c.size_z});
-  if (!c.ae) { L.add("logvar_lin.weight", {c.size_z, prev}); L.add("logvar_lin.bias", {c.size_z}); }
+  L.add(pre + "mu_lin.weight", {c.size_z, prev}); L.add(pre + "mu_lin.bias", {c.size_z});
+  if (c.ae == 0) { L.add("logvar_lin.weight", {c.size_z, prev}); L.add("logvar_lin.bias", {c.size_z}); }
+  if (c.ae == 2) spec_proj_head(L, c.size_z);
   return L.v;
 }
 
@@ -1211,6 +1220,28 @@ bool build_resdec_plan(const ResDecCfg& cfg, int B, int z_ld, const float* const
   }
 }
 
+// ProjectionHead (h_vae_model.py:964-985, eval mode): p = projection(x); y = LayerNorm(fc(GELU(p)) + p).  The first Linear is
+// emitted twice (plain and through GELU: the residual needs p itself), the LayerNorm is GroupNorm(1, d) over the single
+// position and writes the plan's external output.
+static void emit_proj_head(Builder& b, const View& mu, int d) {
+  const float* wp = b.T("proj.projection.weight", (int64_t)d * d); const float* bp = b.T("proj.projection.bias", d);
+  Builder::ConvSpec a; a.name = "proj.projection"; a.a = mu; a.cm = ChanMap::identity(d); a.cin_true = d; a.w = wp; a.bias = bp; a.cout = d;
+  View p = b.emit_conv(a).out;
+  Builder::ConvSpec g = a; g.name = "proj.projection+gelu"; g.act = ACT_GELU;
+  View pg = b.emit_conv(g).out;
+  Builder::ConvSpec f; f.name = "proj.fc+residual"; f.a = pg; f.cm = ChanMap::identity(d); f.cin_true = d;
+  f.w = b.T("proj.fc.weight", (int64_t)d * d); f.bias = b.T("proj.fc.bias", d); f.cout = d; f.has_res = true; f.r = p; f.want_stats = true;
+  Builder::ConvResult rf = b.emit_conv(f);
+  View zero; zero.H = zero.W = 1; zero.C = pad8(d); zero.ld = zero.C;
+  zero.off = b.ws_alloc((int64_t)b.B * zero.ld, /*pin=*/true);   // fresh, never recycled, never written: the workspace is zeroed once at creation
+  Op& op = b.push(OP_GN_RES, "proj.layer_norm");
+  GnResOp& r = op.gr; r.B = b.B; r.u = rf.out; r.x = zero; r.out = rf.out; r.out.off = 0; r.out.ld = d; r.out_ext = 1;
+  r.part_off = rf.stat_off; r.nparts = rf.stat_nparts; r.inv_count = 1.0f / (float)d;
+  r.gamma_off = b.add_params(b.pack_vec(b.T("proj.layer_norm.weight", d), d, nullptr, pad8(d)));
+  r.beta_off = b.add_params(b.pack_vec(b.T("proj.layer_norm.bias", d), d, nullptr, pad8(d)));
+  b.plan->out_C = d;
+}
+
 // ResEncoder / ResEncoderN (h_vae_model_copy.py:41-71, 379-409): conv5x5+BN+LeakyReLU -> AvgPool2 -> RBlocks (each followed
 // by AvgPool(down)) -> channel halves -> mu_lin / logvar_lin on the flattened (c, y, x) features.  The two Linears are one
 // full-image convolution with block-structured weights; output rows are [mu | logvar].
@@ -1218,7 +1249,7 @@ bool build_resenc_plan(const ResDecCfg& cfg, int B, const float* const* tensors,
   try {
     std::vector<TensorSpec> specs = resenc_tensor_specs(cfg);
     Builder b(plan, B, specs, tensors);
-    const bool nvar = cfg.variant != 0;
+    const bool nvar = (cfg.variant & 1) != 0, rep = (cfg.variant & 2) != 0;
     plan->in_C = cfg.img_ch; plan->in_H = plan->in_W = cfg.size_in; plan->in_ld = 0;
     plan->out_C = 2 * cfg.size_z; plan->out_H = plan->out_W = 1;
     View xin = b.new_act(cfg.size_in, cfg.size_in, cfg.img_ch);
@@ -1245,6 +1276,19 @@ bool build_resenc_plan(const ResDecCfg& cfg, int B, const float* const* tensors,
       h = cfg.enc[i][3] > 1 ? pool(o, cfg.enc[i][3], "enc.r_blocks." + std::to_string(i) + ".down_pool") : o;
     }
     const int C = cfg.enc[cfg.n_enc - 1][2], half = C / 2, P = h.H * h.W, sz = cfg.size_z;
+    if (rep) {                                           // Cel{Img,Mask}Rep: mu only, then the projection head
+      if (sz % 8) throw std::runtime_error("plan: projection head width must be a multiple of 8");
+      const float* wm = b.T("enc.mu_lin.weight", (int64_t)sz * half * P);
+      std::vector<float> w((size_t)sz * C * P, 0.f);
+      for (int n = 0; n < sz; ++n) for (int c = 0; c < half; ++c) for (int q = 0; q < P; ++q) w[((size_t)n * C + c) * P + q] = wm[((size_t)n * half + c) * P + q];
+      Builder::ConvSpec fc; fc.name = "enc.mu_lin"; fc.a = h; fc.cm = ChanMap::identity(C); fc.cin_true = C; fc.kh = h.H; fc.kw = h.W; fc.pad = 0;
+      fc.w = w.data(); fc.bias = b.T("enc.mu_lin.bias", sz); fc.cout = sz; fc.Hout = fc.Wout = 1;
+      View mu = b.emit_conv(fc).out;
+      b.free_act(h);
+      emit_proj_head(b, mu, sz);
+      finalize_gemm_tables(plan);
+      return true;
+    }
     const float* wm = b.T("enc.mu_lin.weight", (int64_t)sz * half * P); const float* wl = b.T("enc.logvar_lin.weight", (int64_t)sz * half * P);
     const float* bm = b.T("enc.mu_lin.bias", sz); const float* bl = b.T("enc.logvar_lin.bias", sz);
     std::vector<float> w((size_t)2 * sz * C * P, 0.f), bias(2 * sz);
@@ -1346,13 +1390,14 @@ bool build_attrenc_plan(const AttrEncCfg& cfg, int B, const float* const* tensor
     std::vector<TensorSpec> specs = attrenc_tensor_specs(cfg);
     Builder b(plan, B, specs, tensors);
     const int nout = cfg.ae ? cfg.size_z : 2 * cfg.size_z;
+    const std::string pre = cfg.ae == 2 ? "enc." : "";
     plan->in_C = cfg.att_size; plan->in_H = plan->in_W = 1; plan->in_ld = 0;
     plan->out_C = nout; plan->out_H = plan->out_W = 1;
     View h = b.new_act(1, 1, cfg.att_size);
     { Op& op = b.push(OP_NCHW_TO_PBC, "input"); op.cv.B = B; op.cv.C = cfg.att_size; op.cv.Hn = 1; op.cv.Wn = 1; op.cv.out = h; }
     int prev = cfg.att_size;
     for (int i = 0; i < 5; ++i) {
-      std::string l = "enc_net." + std::to_string(3 * i) + ".", bnp = "enc_net." + std::to_string(3 * i + 1) + ".";
+      std::string l = pre + "enc_net." + std::to_string(3 * i) + ".", bnp = pre + "enc_net." + std::to_string(3 * i + 1) + ".";
       std::vector<double> s, t;
       bn_fold(b, bnp, kAttrEncW[i], &s, &t);
       Builder::ConvSpec c; c.name = l + "+bn+relu"; c.a = h; c.cm = ChanMap::identity(prev); c.cin_true = prev;
@@ -1363,8 +1408,16 @@ bool build_attrenc_plan(const AttrEncCfg& cfg, int B, const float* const* tensor
       h = o; prev = kAttrEncW[i];
     }
     std::vector<float> w((size_t)nout * prev), bias(nout);
-    std::memcpy(w.data(), b.T("mu_lin.weight", (int64_t)cfg.size_z * prev), sizeof(float) * cfg.size_z * prev);
-    std::memcpy(bias.data(), b.T("mu_lin.bias", cfg.size_z), sizeof(float) * cfg.size_z);
+    std::memcpy(w.data(), b.T(pre + "mu_lin.weight", (int64_t)cfg.size_z * prev), sizeof(float) * cfg.size_z * prev);
+    std::memcpy(bias.data(), b.T(pre + "mu_lin.bias", cfg.size_z), sizeof(float) * cfg.size_z);
+    if (cfg.ae == 2) {                                   // CelAttrRep: mu -> projection head
+      Builder::ConvSpec c; c.name = "enc.mu_lin"; c.a = h; c.cm = ChanMap::identity(prev); c.cin_true = prev; c.w = w.data(); c.bias = bias.data(); c.cout = cfg.size_z;
+      View mu = b.emit_conv(c).out;
+      b.free_act(h);
+      emit_proj_head(b, mu, cfg.size_z);
+      finalize_gemm_tables(plan);
+      return true;
+    }
     if (!cfg.ae) {
       std::memcpy(w.data() + (size_t)cfg.size_z * prev, b.T("logvar_lin.weight", (int64_t)cfg.size_z * prev), sizeof(float) * cfg.size_z * prev);
       std::memcpy(bias.data() + cfg.size_z, b.T("logvar_lin.bias", cfg.size_z), sizeof(float) * cfg.size_z);

@@ -117,6 +117,7 @@ struct GnResOp {
   View u, x, out;
   int64_t part_off = 0; int nparts = 0; float inv_count = 0.f;
   int64_t gamma_off = 0, beta_off = 0;
+  int out_ext = 0;        // 1: `out` is the plan's external output [B][out.ld] (LayerNorm tail of the Cel*Rep projection heads)
 };
 
 struct SinusOp { int B = 0; int dim = 0; int64_t out_off = 0; int ld = 0; int64_t freq_off = 0; /* params [dim/2] */ int cos_first = 0; };
@@ -191,7 +192,8 @@ std::vector<TensorSpec> unet_tensor_specs(const UnetCfg& cfg);
 bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Plan* plan);
 
 struct ResDecCfg {
-  int variant = 0;        // 0: ResVAE/ResAE (LeakyReLU, nearest)   1: ResVAEN/ResAEN (GELU, bilinear, sigmoid)
+  int variant = 0;        // bit 0: 0 ResVAE/ResAE (LeakyReLU, nearest), 1 ResVAEN/ResAEN (GELU, bilinear, sigmoid);
+                          // bit 1 (encoder plans): CelImgRep / CelMaskRep = encoder mu -> ProjectionHead (h_vae_model.py:1040-1072)
   int size_in = 32, size_z = 64, img_ch = 3;
   int n_enc = 0; int enc[8][4];
   int n_dec = 0; int dec[8][4];
@@ -219,7 +221,7 @@ std::vector<TensorSpec> mlp_tensor_specs(const MlpCfg& cfg);
 bool build_mlp_plan(const MlpCfg& cfg, int B, const float* const* tensors, Plan* plan);
 
 // CelebAAttrNewBN[AE].encoder (h_vae_model.py:718-736, 756-759; AE :845-863, 884-887): attributes (B, att_size) -> [mu | logvar]
-struct AttrEncCfg { int size_z = 64, att_size = 18, ae = 0; };
+struct AttrEncCfg { int size_z = 64, att_size = 18, ae = 0; };   // ae: 0 VAE (mu|logvar), 1 AE (mu), 2 CelAttrRep (keys under enc., mu -> ProjectionHead, h_vae_model.py:964-1002)
 std::vector<TensorSpec> attrenc_tensor_specs(const AttrEncCfg& cfg);
 bool build_attrenc_plan(const AttrEncCfg& cfg, int B, const float* const* tensors, Plan* plan);
 

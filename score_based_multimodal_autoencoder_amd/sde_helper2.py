@@ -179,8 +179,17 @@ def _alphas_dev(sde, device):
     return cache[key]
 
 
+def _with_z(score_fn, z_cond):
+    """The conditional CelebA script passes z_cond to em_predictor/corrector (train_lat_celebhq_unet_cont2_cond.py:225-226,
+    307-309), which the reference's sde_helper2 does not accept (TypeError as shipped).  Intended meaning, defined
+    here: score_fn(x, t) = UNetModel(x, t, z=z_cond)."""
+    if z_cond is None:
+        return score_fn
+    return lambda x, t: score_fn(x, t, z=z_cond)
+
+
 def em_predictor(x, t, score_fn, sde, probability_flow=False, cl_g=None, cl_s=None, target=None, given=None,
-                 all_mods=None, *, noise=None, score=None):
+                 all_mods=None, z_cond=None, *, noise=None, score=None):
     """One reverse-SDE Euler-Maruyama step -> (x, x_mean)   [reference sde_helper2.py:45-52].
 
     `noise`: the randn_like draw (default: torch.randn_like(x), drawn BEFORE the score call like the reference).
@@ -189,7 +198,7 @@ def em_predictor(x, t, score_fn, sde, probability_flow=False, cl_g=None, cl_s=No
     x = as_f32_cuda(x, "x")
     t = as_f32_cuda(t, "t")
     z = torch.randn_like(x) if noise is None else as_f32_cuda(noise, "noise")
-    s = as_f32_cuda(score_fn(x, t) if score is None else score, "score")
+    s = as_f32_cuda(_with_z(score_fn, z_cond)(x, t) if score is None else score, "score")
     B = x.shape[0]
     x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
     cfg = sde._cfg(probability_flow=probability_flow)
@@ -198,8 +207,8 @@ def em_predictor(x, t, score_fn, sde, probability_flow=False, cl_g=None, cl_s=No
     return x_new, x_mean
 
 
-def corrector(x, t, score_fn, sde, n_steps, target_snr, cl_g=None, cl_s=None, target=None, given=None, all_mods=None, *,
-              noise=None):
+def corrector(x, t, score_fn, sde, n_steps, target_snr, cl_g=None, cl_s=None, target=None, given=None, all_mods=None,
+              z_cond=None, *, noise=None):
     """n_steps Langevin corrector iterations -> (x, x_mean)   [reference sde_helper2.py:54-106].
 
     `noise`: optional list of n_steps injected draws (default torch.randn_like after each score call)."""
@@ -212,7 +221,7 @@ def corrector(x, t, score_fn, sde, n_steps, target_snr, cl_g=None, cl_s=None, ta
     norms = torch.empty(2 * B, device=x.device, dtype=torch.float32)
     x_mean = x
     for i in range(n_steps):
-        g = as_f32_cuda(score_fn(x, t), "score")
+        g = as_f32_cuda(_with_z(score_fn, z_cond)(x, t), "score")
         z = torch.randn_like(x) if noise is None else as_f32_cuda(noise[i], "noise")
         x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
         _lib.check(_lib.lib().sbm_langevin_step(ctypes.byref(cfg), x.data_ptr(), g.data_ptr(), z.data_ptr(), t.data_ptr(),
@@ -223,14 +232,17 @@ def corrector(x, t, score_fn, sde, n_steps, target_snr, cl_g=None, cl_s=None, ta
     return x, x_mean
 
 
-def _fused_ok(model):
+def _fused_ok(model, z_cond=None):
     from .unet_model import Unet
-    return isinstance(model, Unet) and model.with_time_emb
+    from .unet_openai import UNetModel
+    if isinstance(model, UNetModel):
+        return not model.training or not model.dropout
+    return isinstance(model, Unet) and model.with_time_emb and z_cond is None
 
 
 def uncond_sampler(sample_shape, model, device, sde, eps=1e-3, probability_flow=False, pc=False, n_steps=1,
                    target_snr=0.16, cl_g=None, cl_s=None, target=None, *, order="cp", noise=None, x0=None, seed=None,
-                   sample_offset=0, use_graph=True, return_timing=False):
+                   sample_offset=0, use_graph=True, return_timing=False, z_cond=None):
     """N-step predictor(-corrector) sampling; returns the last sub-step's x_mean   [reference sde_helper2.py:115-128]."""
     _no_guidance(cl_g)
     if order not in ("cp", "pc"):
@@ -249,8 +261,14 @@ def uncond_sampler(sample_shape, model, device, sde, eps=1e-3, probability_flow=
             noise = as_f32_cuda(noise, "noise")
             if noise.shape[0] < sde.N * dps:
                 raise ValueError(f"noise needs {sde.N * dps} draws")
-        if _fused_ok(model):
-            eng = model._engine_for(B, x.shape[2], x.shape[3])
+        if _fused_ok(model, z_cond):
+            from .unet_openai import UNetModel
+            if isinstance(model, UNetModel):
+                eng = model._engine_for(B, x.shape[2], x.shape[3], z_cond is not None)
+                zc = as_f32_cuda(z_cond, "z_cond") if z_cond is not None else None
+                _lib.check(_lib.lib().sbm_model_set_aux(eng.h, zc.data_ptr() if zc is not None else None))
+            else:
+                eng = model._engine_for(B, x.shape[2], x.shape[3])
             cfg = sde._cfg(target_snr=target_snr, probability_flow=probability_flow)
             if seed is None:
                 seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
@@ -275,13 +293,13 @@ def uncond_sampler(sample_shape, model, device, sde, eps=1e-3, probability_flow=
                 nonlocal k
                 nz = None if noise is None else [noise[k + j] for j in range(n_steps)]
                 k += n_steps if noise is not None else 0
-                return corrector(x, vec_t, model, sde, n_steps, target_snr, noise=nz)
+                return corrector(x, vec_t, model, sde, n_steps, target_snr, z_cond=z_cond, noise=nz)
 
             def pred(x):
                 nonlocal k
                 nz = None if noise is None else noise[k]
                 k += 1 if noise is not None else 0
-                return em_predictor(x, vec_t, model, sde, probability_flow, noise=nz)
+                return em_predictor(x, vec_t, model, sde, probability_flow, z_cond=z_cond, noise=nz)
 
             if order == "cp":
                 if pc:
@@ -311,7 +329,8 @@ def renoise_observed(x, z_obs, t, sde, given, out=None):
     return out
 
 
-def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target_snr=0.16, noise_obs=False, *, x0=None, noise=None):
+def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target_snr=0.16, noise_obs=False, *, x0=None, noise=None,
+                 z_cond=None):
     """Conditional generation loop of the training scripts' evaluate() (train_poly_unet_cont.py:340-381,
     train_lat_celebhq_unet_cont2.py:277-318): channels in `given` hold the observed latents z_obs (re-noised to level t at
     every step when noise_obs), the others start from N(0,1) (or x0) and follow the reverse SDE, predictor then corrector.
@@ -334,10 +353,10 @@ def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target
             x_in = renoise_observed(x, z_obs, vec_t, sde, given) if noise_obs else torch.where(keep, z_obs, x)
             nz = None if noise is None else noise[k]
             k += 1
-            x_upd, x_mean = em_predictor(x_in, vec_t, model, sde, noise=nz)
+            x_upd, x_mean = em_predictor(x_in, vec_t, model, sde, z_cond=z_cond, noise=nz)
             if pc:
                 nzs = None if noise is None else [noise[k + j] for j in range(n_steps)]
                 k += n_steps
-                x_upd, x_mean = corrector(x_upd, vec_t, model, sde, n_steps, target_snr, noise=nzs)
+                x_upd, x_mean = corrector(x_upd, vec_t, model, sde, n_steps, target_snr, z_cond=z_cond, noise=nzs)
             x = x_upd
         return torch.where(keep, z_obs, x_mean)

@@ -27,6 +27,11 @@ class UNetModel(ParamTreeModule):
         self._build_tree(arch.unet_openai_entries(in_channels, model_channels, out_channels, num_res_blocks,
                                                   self.attention_resolutions, self.channel_mult, z_dim, self.use_z))
 
+    def _engine_for(self, B, H, W, with_z):
+        cfg = _lib.unet_oa_cfg_ints(self.in_channels, self.model_channels, self.out_channels, self.num_res_blocks,
+                                    self.attention_resolutions, self.channel_mult, H, W, self.num_heads, self.z_dim, self.use_z)
+        return self._engine(("oa", B, H, W, with_z), lambda sd: _lib.Engine(_lib.SBM_UNET_OA, cfg, B, sd, in_pitch=int(with_z)))
+
     def forward(self, x, timesteps, z=None, y=None, **kwargs):
         """x (B, in_channels, H, W), timesteps (B,), z (B, z_dim) or None -> (B, out_channels, H, W)  [unet_openai.py:538]"""
         if y is not None:
@@ -43,8 +48,6 @@ class UNetModel(ParamTreeModule):
                 raise AssertionError("z given but the model has no proj (use_z=False)")       # reference asserts too (:556)
             z = as_f32_cuda(z, "z")
             assert tuple(z.shape) == (B, self.z_dim)
-        cfg = _lib.unet_oa_cfg_ints(self.in_channels, self.model_channels, self.out_channels, self.num_res_blocks,
-                                    self.attention_resolutions, self.channel_mult, H, W, self.num_heads, self.z_dim, self.use_z)
-        eng = self._engine(("oa", B, H, W, with_z), lambda sd: _lib.Engine(_lib.SBM_UNET_OA, cfg, B, sd, in_pitch=int(with_z)))
+        eng = self._engine_for(B, H, W, with_z)
         out = torch.empty((B, self.out_channels, H, W), device=x.device, dtype=torch.float32)
         return eng.forward_aux(x, t, z, out)

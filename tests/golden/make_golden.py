@@ -412,6 +412,12 @@ def encoder_cases():
         out[f"{name}_mu"] = (e[0] if isinstance(e, tuple) else e).numpy()
         if isinstance(e, tuple):
             out[f"{name}_logvar"] = e[1].numpy()
+    # conditioning encoders of the conditional CelebA score model (h_vae_model.py:987-1072)
+    from h_vae_model import CelAttrRep, CelImgRep, CelMaskRep  # noqa: E402  (reference)
+    for name, m, shape in (("CelAttrRep", CelAttrRep(18, 512), (3, 18)), ("CelImgRep", CelImgRep(512), (1, 3, 128, 128)), ("CelMaskRep", CelMaskRep(512), (1, 1, 128, 128))):
+        m = synth.fill_module_(m.eval())
+        x = (inp(f"rep.{name}.x", shape) > 0).astype(np.float32) if len(shape) == 2 else inp(f"rep.{name}.x", shape, 0.25) + 0.5
+        out[f"{name}_x"], out[f"{name}_y"] = x, m(torch.from_numpy(x)).numpy()
     for name, cls in (("AttrBN", CelebAAttrNewBN), ("AttrBNAE", CelebAAttrNewBNAE)):
         m = cls(256).eval()
         synth.fill_module_(m)

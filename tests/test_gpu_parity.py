@@ -436,3 +436,56 @@ def test_attr_encoders(pkg, golden, name):
     assert_close(mu, g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
     if isinstance(e, tuple):
         assert_close(e[1].cpu().numpy(), g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")
+
+
+@pytest.mark.parametrize("with_z,pc", [(True, False), (True, True), (False, False)])
+def test_unet_openai_sampler_with_z_cond(pkg, with_z, pc):
+    """Conditional CelebA path: z_cond reaches the score net as UNetModel(x, t, z=z_cond); the fused device
+    loop and the step-by-step em_predictor/corrector calls give the same trajectory."""
+    from score_based_multimodal_autoencoder_amd.unet_openai import UNetModel
+    S = pkg["sde"]
+    kw = OA_CASES["oa_tiny"]
+    m = UNetModel(kw["in_channels"], kw["model_channels"], kw["out_channels"], kw["num_res_blocks"], kw["attention_resolutions"], 0.1,
+                  kw["channel_mult"], num_heads=1, use_z=True, z_dim=kw["z_dim"]).eval()
+    pkg["synth"].fill_module_(m)
+    m = m.cuda()
+    B, N = 4, 6
+    sde = S.VPSDE(0.1, 5.0, N)
+    x0 = torch.randn(B, 3, 8, 8, device="cuda")
+    z = torch.randn(B, kw["z_dim"], device="cuda") if with_z else None
+    dps = 2 if pc else 1
+    noise = torch.randn(N * dps, B, 3, 8, 8, device="cuda")
+    fused = S.uncond_sampler((B, 3, 8, 8), m, "cuda", sde, pc=pc, x0=x0, noise=noise, z_cond=z)
+    # the same loop through the per-step API (order 'cp': corrector first, then predictor -- sde_helper2.py:115-128)
+    x = x0.clone()
+    ts = torch.linspace(sde.T, 1e-3, N, device="cuda")
+    k = 0
+    for i in range(N):
+        vt = torch.ones(B, device="cuda") * ts[i]
+        if pc:
+            x, xm = S.corrector(x, vt, m, sde, 1, 0.16, z_cond=z, noise=[noise[k]]); k += 1
+        x, xm = S.em_predictor(x, vt, m, sde, z_cond=z, noise=noise[k]); k += 1
+    assert torch.isfinite(xm).all(), "the synthetic score net must keep this short chain finite"
+    torch.testing.assert_close(fused, xm, rtol=1e-5, atol=1e-5)
+    if with_z:
+        other = S.uncond_sampler((B, 3, 8, 8), m, "cuda", sde, pc=pc, x0=x0, noise=noise, z_cond=torch.zeros_like(z))
+        assert not torch.allclose(other, fused)
+
+
+def test_cel_rep_conditioning_encoders(pkg, golden):
+    """CelAttrRep / CelImgRep / CelMaskRep (encoder mu -> ProjectionHead) and get_conds."""
+    g = golden("encoders.npz")
+    H = pkg["attr"]
+    models = {}
+    for name, m in (("CelAttrRep", H.CelAttrRep(18, 512)), ("CelImgRep", H.CelImgRep(512)), ("CelMaskRep", H.CelMaskRep(512))):
+        pkg["synth"].fill_module_(m.eval())
+        m = m.cuda()
+        models[name] = m
+        y = m(dev(g[f"{name}_x"])).cpu().numpy()
+        assert_close(y, g[f"{name}_y"], 1e-5, 1e-5 * np.abs(g[f"{name}_y"]).max(), name)
+    conds = [models["CelImgRep"], models["CelMaskRep"], models["CelAttrRep"]]
+    xs = [dev(g["CelImgRep_x"]), dev(g["CelMaskRep_x"]), dev(g["CelAttrRep_x"][:1])]
+    z = H.get_conds(xs, conds, "02")
+    want = (g["CelImgRep_y"] + g["CelAttrRep_y"][:1]) / 2
+    assert_close(z.cpu().numpy(), want, 1e-5, 1e-5 * np.abs(want).max(), "get_conds")
+    assert H.get_conds(xs, conds, "") is None

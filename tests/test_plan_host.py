@@ -172,3 +172,16 @@ def test_attr_encoder_plan(golden, name, ae):
     assert_close(y[:, :256], g[f"{name}_mu"], 1e-5, 1e-5 * np.abs(g[f"{name}_mu"]).max(), name + " mu")
     if not ae:
         assert_close(y[:, 256:], g[f"{name}_logvar"], 1e-5, 1e-5 * np.abs(g[f"{name}_logvar"]).max(), name + " logvar")
+
+
+def test_cel_rep_plans(golden):
+    """CelAttrRep / CelMaskRep: encoder mu -> ProjectionHead (Linear, GELU, Linear, +residual, LayerNorm) on the host interpreter."""
+    g = golden("encoders.npz")
+    sd = synth.fill_state_dict(dict(arch.cel_attr_rep_entries(18, 512)))
+    x = g["CelAttrRep_x"]
+    y = planref.RefPlan(6, [512, 18, 2], x.shape[0], sd).run(x.reshape(x.shape[0], 18, 1, 1), None, (x.shape[0], 512))
+    assert_close(y, g["CelAttrRep_y"], 1e-5, 1e-5 * np.abs(g["CelAttrRep_y"]).max(), "CelAttrRep")
+    sd = synth.fill_state_dict(dict(arch.cel_rep_entries(arch.CEL_MASK_REP_ENC, 512, 1, 128)))
+    x = g["CelMaskRep_x"]
+    y = planref.RefPlan(5, planref.resdec_cfg_ints(3, arch.CEL_MASK_REP_ENC, [], 128, 512, 1), 1, sd).run(x, None, (1, 512))
+    assert_close(y, g["CelMaskRep_y"], 1e-5, 1e-5 * np.abs(g["CelMaskRep_y"]).max(), "CelMaskRep")
