@@ -614,6 +614,14 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
     if (exec) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); }
     if (se != hipSuccess) return fail_hip("hipStreamSynchronize", se);
     if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, m->ev_t0, m->ev_t1));
+    if (m->d_chain_sync) {                                     // a chain-kernel barrier that timed out invalidates the run: say so, loudly
+      unsigned flag = 0;
+      HIPCHK(hipMemcpy(&flag, &m->d_chain_sync->abort_flag, sizeof(unsigned), hipMemcpyDeviceToHost));
+      if (flag) {
+        (void)hipMemset(m->d_chain_sync, 0, sizeof(ChainSync));
+        return fail("sbm_sampler_run: a chain-kernel barrier timed out (not every workgroup was resident?); results are invalid");
+      }
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;

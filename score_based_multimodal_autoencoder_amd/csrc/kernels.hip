@@ -16,6 +16,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 // Profiling hook: when an event pair is armed (sbm_model_profile), the next launch carries it on its own dispatch packet, so
 // hipEventElapsedTime(start, stop) is the kernel's begin->end time (what rocprofv3 --kernel-trace reports), free of the
 // dispatch latency that a hipEventRecord pair around the launch would include.
@@ -498,6 +500,73 @@ __global__ __launch_bounds__(256) void dwconv7_kernel(const DwArgs d) {
       float ss = 0.f, qq = 0.f;
       for (int i = 0; i < d.lanes; ++i) { ss += red[tid + i].x; qq += red[tid + i].y; }
       d.stat[(long long)p * d.B + b] = make_float2(ss, qq);
+    }
+  }
+}
+
+// W == 8 variant: a thread owns (sample, channel quad) and FOUR horizontally adjacent outputs (half an output row), so that the
+// 7 input pixels of a window row are loaded once for the four windows that share them (12 loads per output instead of ~30).
+// Taps are accumulated in the same (ky, kx) order as dwconv7_kernel: the results are bit-identical.
+template <int HALF>
+__device__ __forceinline__ void dw8_half_row(const DwArgs& d, int oy, int b, int c, float4* acc) {
+  const int ky0 = max(0, 3 - oy), ky1 = min(7, d.H + 3 - oy);
+  constexpr int XB = HALF ? 1 : 0;                               // first input column of the 7 this half row can touch
+  for (int ky = ky0; ky < ky1; ++ky) {
+    const int iy = oy - 3 + ky;
+    float4 x[7], w[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      x[j] = *reinterpret_cast<const float4*>(d.in + ((long long)(iy * 8 + XB + j) * d.B + b) * d.ldi + c);
+      w[j] = *reinterpret_cast<const float4*>(d.w + (ky * 7 + j) * d.C + c);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        constexpr int dummy = 0; (void)dummy;
+        const int j = o + kx - (HALF ? 0 : 3);                    // input column (relative to XB) under tap kx of output 4*HALF + o
+        if (j >= 0 && j < 7) {
+          acc[o].x = fmaf(x[j].x, w[kx].x, acc[o].x); acc[o].y = fmaf(x[j].y, w[kx].y, acc[o].y);
+          acc[o].z = fmaf(x[j].z, w[kx].z, acc[o].z); acc[o].w = fmaf(x[j].w, w[kx].w, acc[o].w);
+        }
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void dwconv7_w8_kernel(const DwArgs d) {
+  __shared__ float2 red[4][256];
+  const int tid = threadIdx.x;
+  const int oy = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int sl = tid / d.lanes, cl = tid - sl * d.lanes;         // lanes == C/4 here: one channel quad per thread
+  const int b = blockIdx.y * d.spb + sl;
+  const bool active = sl < d.spb && b < d.B;
+  const int c = cl * 4;
+  float4 acc[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    if (half) dw8_half_row<1>(d, oy, b, c, acc); else dw8_half_row<0>(d, oy, b, c, acc);
+    const float4 bi = *reinterpret_cast<const float4*>(d.bias + c);
+    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.cond) cv = *reinterpret_cast<const float4*>(dw_cond_row(d, b) + c);
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      acc[o].x += bi.x; acc[o].y += bi.y; acc[o].z += bi.z; acc[o].w += bi.w;
+      if (d.cond) { acc[o].x += cv.x; acc[o].y += cv.y; acc[o].z += cv.z; acc[o].w += cv.w; }
+      const int p = oy * 8 + half * 4 + o;
+      *reinterpret_cast<float4*>(d.out + ((long long)p * d.B + b) * d.ldo + c) = acc[o];
+    }
+  }
+  if (d.stat) {
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+      red[o][tid] = active ? make_float2(acc[o].x + acc[o].y + acc[o].z + acc[o].w, acc[o].x * acc[o].x + acc[o].y * acc[o].y + acc[o].z * acc[o].z + acc[o].w * acc[o].w)
+                           : make_float2(0.f, 0.f);
+    __syncthreads();
+    if (active && cl < 4) {                                      // four threads of the sample, one output pixel each
+      float ss = 0.f, qq = 0.f;
+      for (int i = 0; i < d.lanes; ++i) { ss += red[cl][tid - cl + i].x; qq += red[cl][tid - cl + i].y; }
+      d.stat[(long long)(oy * 8 + half * 4 + cl) * d.B + b] = make_float2(ss, qq);
     }
   }
 }
@@ -1016,8 +1085,12 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
     case OP_GEMM: return launch_gemm(op.g, dp.hot[idx], ext_in, ext_out, st);
     case OP_DWCONV7: {
       const DwOp& o = op.dw; const DwArgs d = make_dw_args(plan, o, prm, ws, dp.ctl);
-      dim3 grid(o.in.H * o.in.W, ceil_div(o.B, d.spb));
-      SBM_KLAUNCH(dwconv7_kernel, grid, dim3(256), 0, st, d);
+      if (o.in.W == 8 && o.in.C / 4 <= 64 && o.in.C / 4 >= 4 && (256 % (o.in.C / 4)) == 0 && !getenv("SBM_NO_DW8")) {
+        SBM_KLAUNCH(dwconv7_w8_kernel, dim3(o.in.H * 2, ceil_div(o.B, d.spb)), dim3(256), 0, st, d);
+      } else {
+        dim3 grid(o.in.H * o.in.W, ceil_div(o.B, d.spb));
+        SBM_KLAUNCH(dwconv7_kernel, grid, dim3(256), 0, st, d);
+      }
     } break;
     case OP_LINATTN: case OP_ATTN: {
       const AttnOp& o = op.at; const AttnArgs a = make_attn_args(o, ws);
