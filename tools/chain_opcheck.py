@@ -34,7 +34,8 @@ for rep in range(1):
     bad = err > 3e-5 * scale
     if bad.any():
         idx = np.flatnonzero(changed)[bad]
-        print(f"ops [{i},{i+STEP}) {[ref.op_name(j) for j in range(i, min(i + STEP, ref.info[chr(110)+chr(95)+chr(111)+chr(112)+chr(115)]))]}: {bad.sum()}/{bad.size} bad, max err {err.max():.3e} scale {scale:.3e}; first bad ws offsets {idx[:6]} .. {idx[-3:]}", flush=True)
+        names = [ref.op_name(j) for j in range(i, min(i + STEP, ref.info["n_ops"]))]
+        print(f"ops [{i},{i+STEP}) {names}: {bad.sum()}/{bad.size} bad, max err {err.max():.3e} scale {scale:.3e}; first bad ws offsets {idx[:6]} .. {idx[-3:]}", flush=True)
         # resync the GPU workspace from the reference is not possible; stop at the first failure
         sys.exit(1)
 print("all ops match")
