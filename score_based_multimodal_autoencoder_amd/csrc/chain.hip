@@ -187,6 +187,40 @@ DEVINL void stage_frag(const Frag& f, float* tile, int lane, float* a) {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the tile may be overwritten by the next chunk
 }
 
+// Hand-counted variant for the K-split loop: B first (4 cached 16-byte loads), then A (4 L1-bypassing 16-byte loads, eight
+// lanes per 128-byte row -- 8-byte sc1 loads run at 0.54-0.70x the 16-byte rate), all issued by inline asm so that the wait in
+// front of a chunk is exactly "everything but the next chunk's eight loads" instead of whatever the compiler's scoreboard
+// makes of a loop with conditional refills.  The fragments stay in their slots (never copied) until wait_fragm names them.
+struct FragM { f32x4n a[4]; f32x4n w[4]; };
+
+DEVINL void load_fragm(FragM& f, const GemmHot& g, const int4 d, int b0, int B, int lane, int brow, int fh) {
+  const bool s2 = (d.w & 1) != 0;
+  const int lda = s2 ? g.lda2 : g.lda;
+  const float* ap = (s2 ? g.A2 : g.A) + d.x + (lane & 7) * 4;
+  const float* wp = (s2 ? g.W2 : g.W) + d.y + (long long)brow * (s2 ? g.Kp2 : g.Kp) + 16 * fh;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.w[j]) : "v"(wp + 4 * j) : "memory");
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* p = ap + (long long)min(b0 + (lane >> 3) + 8 * i, B - 1) * lda;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(f.a[i]) : "v"(p) : "memory");
+  }
+}
+// younger: the next chunk's eight loads were issued after this chunk's and may stay in flight
+DEVINL void wait_fragm(FragM& f, bool younger) {
+  if (younger) asm volatile("s_waitcnt vmcnt(8)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+}
+DEVINL void stage_fragm(const FragM& f, float* tile, int lane, float* a) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4n*>(tile + ((lane >> 3) + 8 * i) * A_LD + (lane & 7) * 4) = f.a[i];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float* rp = tile + (lane & 31) * A_LD + 16 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float4 v = *reinterpret_cast<const float4*>(rp + 4 * j); a[4 * j] = v.x; a[4 * j + 1] = v.y; a[4 * j + 2] = v.z; a[4 * j + 3] = v.w; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // Short-K GEMMs (1x1 convolutions, the 1x1 level): one unit per WAVE, the whole K walked by that wave -- no K split, no
 // cross-wave reduction, no workgroup barrier inside the unit loop, and up to 8 x 32 units in flight per cluster instead of 32.
 DEVINL void chain_gemm_wpu(const GemmHot& g, const GemmCold& cold, int P, bool gn, Ctx& c) {
@@ -347,18 +381,19 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
       const int first = lo + c.wave;
       if (first >= hi) return;
       const int nk = (hi - first + NW - 1) / NW;
-      Frag f[PF];
+      FragM f[PF];
 #pragma unroll
-      for (int sI = 0; sI < PF; ++sI) if (sI < nk) load_frag(f[sI], g, sload16(dsc + first + sI * NW), c.b0, c.B, c.lane, brow, fh);
+      for (int sI = 0; sI < PF; ++sI) if (sI < nk) load_fragm(f[sI], g, sload16(dsc + first + sI * NW), c.b0, c.B, c.lane, brow, fh);
       for (int k = 0; k < nk; k += PF) {
 #pragma unroll
         for (int sI = 0; sI < PF; ++sI) {
           if (k + sI < nk) {
             float av[16];
-            stage_frag(f[sI], atile, c.lane, av);
+            wait_fragm(f[sI], k + sI + 1 < nk);
+            stage_fragm(f[sI], atile, c.lane, av);
 #pragma unroll
-            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], f[sI].w[j], acc, 0, 0, 0);
-            if (k + sI + PF < nk) load_frag(f[sI], g, sload16(dsc + first + (k + sI + PF) * NW), c.b0, c.B, c.lane, brow, fh);
+            for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], f[sI].w[j >> 2][j & 3], acc, 0, 0, 0);
+            if (k + sI + PF < nk) load_fragm(f[sI], g, sload16(dsc + first + (k + sI + PF) * NW), c.b0, c.B, c.lane, brow, fh);
           }
         }
       }
