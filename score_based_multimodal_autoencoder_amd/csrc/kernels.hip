@@ -693,13 +693,15 @@ __global__ __launch_bounds__(64) void linattn_lds_kernel(const AttnArgs a) {
   }
 }
 
-// 16 < n <= 64: four waves per (sample, head).  q/k/v staged once in LDS; every wave forms the k-softmax statistics (cheap,
-// redundant), accumulates the context over its quarter of the pixels, the four partial contexts are added in wave order,
-// and each wave then produces its quarter of the output pixels.
+// 16 < n <= 64: four waves per (sample, head).  q/k/v staged once in LDS; both softmaxes are then applied IN PLACE with every
+// exponential evaluated exactly once (256 threads share them: expf is the expensive instruction sequence here): k over the
+// pixels per channel (8 thread groups per channel, combined through LDS), q over the channels per pixel (4 threads per pixel).
+// Each wave accumulates the context over its quarter of the pixels, the four partial contexts are added in wave order, and
+// each wave produces its quarter of the output pixels.
 __global__ __launch_bounds__(256) void linattn_lds4_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) float sq[64 * 32], sk[64 * 32], sv[64 * 32];      // [pixel][d]
   __shared__ float pctx[4][32][33];
-  __shared__ float qs[4][2][32];
+  __shared__ float kred[8][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = lane & 31, half = lane >> 5;
   const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
   const int hd = a.heads * 32;
@@ -713,19 +715,51 @@ __global__ __launch_bounds__(256) void linattn_lds4_kernel(const AttnArgs a) {
     reinterpret_cast<float4*>(sv)[idx] = *reinterpret_cast<const float4*>(r + 2 * hd);
   }
   __syncthreads();
-  float kmax = -INFINITY;
-  for (int i = half; i < a.n; i += 2) kmax = fmaxf(kmax, sk[i * 32 + d]);
-  kmax = fmaxf(kmax, __shfl_xor(kmax, 32));
-  float ksum = 0.f;
-  for (int i = half; i < a.n; i += 2) ksum += expf(sk[i * 32 + d] - kmax);
-  ksum += __shfl_xor(ksum, 32);
+  // ---- k: softmax over the pixels, per channel kd; thread group kg takes pixels kg, kg + 8, ...
+  const int kd = tid & 31, kg = tid >> 5;
+  float m = -INFINITY;
+  for (int i = kg; i < a.n; i += 8) m = fmaxf(m, sk[i * 32 + kd]);
+  kred[kg][kd] = m;
+  __syncthreads();
+  float kmax = kred[0][kd];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) kmax = fmaxf(kmax, kred[g][kd]);
+  __syncthreads();
+  float ps = 0.f;
+  for (int i = kg; i < a.n; i += 8) { const float e = expf(sk[i * 32 + kd] - kmax); sk[i * 32 + kd] = e; ps += e; }
+  kred[kg][kd] = ps;
+  // ---- q: softmax over the channels, per pixel; 4 threads per pixel, 8 channels each; scaled
+  {
+    const int qi = tid >> 2, part = tid & 3;
+    if (qi < a.n) {
+      float* qp = sq + qi * 32 + part * 8;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = qp[j];
+      float qm = v[0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) qm = fmaxf(qm, v[j]);
+      qm = fmaxf(qm, __shfl_xor(qm, 1)); qm = fmaxf(qm, __shfl_xor(qm, 2));
+      float qsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = expf(v[j] - qm); qsum += v[j]; }
+      qsum += __shfl_xor(qsum, 1); qsum += __shfl_xor(qsum, 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qp[j] = v[j] / qsum * a.scale;
+    }
+  }
+  __syncthreads();
+  float ksum = kred[0][d];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) ksum += kred[g][d];
   const float kinv = 1.0f / ksum;
+  // ---- context over this wave's quarter of the pixels
   const int per = (a.n + 3) / 4, i_lo = wave * per, i_hi = min(a.n, i_lo + per);
   float c[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) c[e] = 0.f;
   for (int i = i_lo; i < i_hi; ++i) {
-    const float kv = expf(sk[i * 32 + d] - kmax) * kinv;
+    const float kv = sk[i * 32 + d] * kinv;
     const float* vrow = sv + i * 32 + half * 16;
 #pragma unroll
     for (int e = 0; e < 16; ++e) c[e] = fmaf(kv, vrow[e], c[e]);
@@ -736,24 +770,13 @@ __global__ __launch_bounds__(256) void linattn_lds4_kernel(const AttnArgs a) {
   float col[32];
 #pragma unroll
   for (int dd = 0; dd < 32; ++dd) col[dd] = ((pctx[0][dd][d] + pctx[1][dd][d]) + pctx[2][dd][d]) + pctx[3][dd][d];
-  for (int i0 = i_lo; i0 < i_hi; i0 += 2) {
-    const int i = i0 + half;
-    const bool ok = i < i_hi;
-    const float qv = ok ? sq[i * 32 + d] : 0.f;
-    float m = qv;
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    const float e = expf(qv - m);
-    float s = e;
-#pragma unroll
-    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-    qs[wave][half][d] = e / s * a.scale;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // wave-private exchange: LDS is in order within a wave
+  // ---- out[i][e = d] = sum_dd ctx[dd][e] * softmax(q)[i][dd] * scale for this wave's pixels; the halves take alternate pixels
+  for (int i = i_lo + half; i < i_hi; i += 2) {
+    const float* qrow = sq + i * 32;
     float o = 0.f;
 #pragma unroll
-    for (int dd = 0; dd < 32; ++dd) o = fmaf(col[dd], qs[wave][half][dd], o);
-    if (ok) a.out[((long long)i * a.B + b) * a.ldo + h * 32 + d] = o;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int dd = 0; dd < 32; ++dd) o = fmaf(col[dd], qrow[dd], o);
+    a.out[((long long)i * a.B + b) * a.ldo + h * 32 + d] = o;
   }
 }
 
