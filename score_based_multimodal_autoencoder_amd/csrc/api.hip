@@ -145,6 +145,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   if ((e = hipMemcpy(m->d_params, m->plan.params.data(), pbytes, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(params)", e); }
   if ((e = hipMemset(m->d_ws, 0, wbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemset(workspace)", e); }
   std::vector<float>().swap(m->plan.params);          // host copy no longer needed
+  for (int i = 0; i + 1 < (int)m->plan.ops.size(); ++i) if (qkv_linattn_fusable(m->plan, i)) m->plan.ops[i].fuse_next = 1;
   if (kind == SBM_UNET || kind == SBM_UNET_OA) {
     if ((e = hipMalloc(&m->d_counter, 64)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(counter)", e); }
     (void)hipMemset(m->d_counter, 0, 64);
@@ -406,7 +407,11 @@ int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev,
       if (skip_time && m->plan.ops[i].time_path) { ++i; continue; }
       const size_t l = bucket.size();
       arm_profile_events(ev[2 * l], ev[2 * l + 1]);            // events ride on the kernel's own dispatch: begin -> end of the kernel
-      if (m->plan.ops[i].chain) {
+      if (m->plan.ops[i].fuse_next) {
+        e = launch_qkv_linattn(m->dp, i, st);
+        bucket.push_back(OP_LINATTN);
+        n = 2;
+      } else if (m->plan.ops[i].chain) {
         while (i + n < nops && m->plan.ops[i + n].chain && !(skip_time && m->plan.ops[i + n].time_path)) ++n;
         if (n > CHAIN_MAX_OPS) n = CHAIN_MAX_OPS;              // one launch per event pair
         e = launch_chain(m->dp, i, n, st);
@@ -435,13 +440,14 @@ int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev,
 // time path (not launched per step inside sbm_sampler_run).
 int sbm_model_gemm_flops(const sbm_model* m, double* out4) {
   if (!m || !out4) return fail("sbm_model_gemm_flops: bad arguments");
-  double chain = 0.0, chain_t = 0.0, seg_t = m->plan.flops_dense_cond;
+  double chain = 0.0, chain_t = 0.0, seg_t = m->plan.flops_dense_cond, other = 0.0;
   for (const Op& op : m->plan.ops) {
     if (op.kind != OP_GEMM) continue;
     if (op.chain) { chain += op.flops_dense; if (op.time_path) chain_t += op.flops_dense; }
     else if (op.time_path) seg_t += op.flops_dense;
+    else if (op.fuse_next) other += op.flops_dense;           // executed inside linattn_qkv_kernel
   }
-  out4[0] = m->plan.flops_dense_gemm - chain; out4[1] = chain; out4[2] = seg_t; out4[3] = chain_t;
+  out4[0] = m->plan.flops_dense_gemm - chain - other; out4[1] = chain; out4[2] = seg_t; out4[3] = chain_t;
   return 0;
 }
 

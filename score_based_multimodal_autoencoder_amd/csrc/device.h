@@ -88,6 +88,8 @@ struct DevPlan {
   const StepCtl* ctl = nullptr;         // sampler control block (score nets)
 };
 const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st);
+bool qkv_linattn_fusable(const Plan& plan, int i);            // ops i (to_qkv GEMM) and i + 1 (LinearAttention core)
+const char* launch_qkv_linattn(const DevPlan& dp, int i, hipStream_t st);
 const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, float* ws, const GemmCold* cold_dev, GemmHot* hot, GemmCold* cold);
 
 // Enqueue every op of the plan on `st`.  Returns nullptr or a static error string.  No allocation, no

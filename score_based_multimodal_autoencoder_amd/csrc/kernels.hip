@@ -780,6 +780,149 @@ __global__ __launch_bounds__(256) void linattn_lds4_kernel(const AttnArgs a) {
   }
 }
 
+// to_qkv (1x1 conv with the GroupNorm in front folded in, 64 input channels) + the LinearAttention core for one (sample, head),
+// n = 64 pixels: the head's q, k, v (64 px x 96) are produced by MFMA straight into the LDS tiles the core works on, instead
+// of a 25 MB round trip through memory and a launch of their own.  Same formulas as seg_gemm's folded GroupNorm epilogue and
+// linattn_lds4_kernel.
+struct QkvAttnArgs {
+  AttnArgs a;                     // out, B, n, ldo, heads, scale (qkv / ldq unused)
+  const float* A; int lda;        // block input h: [pixel][B][lda], 64 channels
+  const float* W;                 // packed to_qkv weights [Npad][Kp = 64] (gamma folded)
+  const float* bias;              // or null
+  const float2* gn_part; int gn_nparts; float gn_inv;
+  const float* gn_s; const float* gn_b1; int Npad;
+};
+
+__global__ __launch_bounds__(256) void linattn_qkv_kernel(const QkvAttnArgs qa) {
+  const AttnArgs& a = qa.a;
+  __shared__ __attribute__((aligned(16))) float sq[64 * 32], sk[64 * 32], sv[64 * 32];      // [pixel][d]
+  __shared__ __attribute__((aligned(16))) float ht[64 * 68];                                 // block input tile [pixel][64 + 4]
+  __shared__ float pctx[4][32][33];
+  __shared__ float kred[8][32];
+  __shared__ double sred[2][4];
+  __shared__ float2 s_mr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+  const int hd = a.heads * 32;
+  // ---- GroupNorm statistics of sample b from the producer's partials
+  {
+    double s = 0.0, q = 0.0;
+    for (int i = tid; i < qa.gn_nparts; i += 256) { const float2 v = qa.gn_part[(long long)i * a.B + b]; s += (double)v.x; q += (double)v.y; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane == 0) { sred[0][wave] = s; sred[1][wave] = q; }
+  }
+  // ---- block input tile: 64 pixels x 64 channels, 16 float4 per pixel row
+  for (int idx = tid; idx < 64 * 16; idx += 256) {
+    const int p = idx >> 4, c4 = (idx & 15) * 4;
+    *reinterpret_cast<float4*>(ht + p * 68 + c4) = *reinterpret_cast<const float4*>(qa.A + ((long long)p * a.B + b) * qa.lda + c4);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double ss = ((sred[0][0] + sred[0][1]) + sred[0][2]) + sred[0][3], qq = ((sred[1][0] + sred[1][1]) + sred[1][2]) + sred[1][3];
+    const double mean = ss * (double)qa.gn_inv;
+    double var = qq * (double)qa.gn_inv - mean * mean; var = var < 0.0 ? 0.0 : var;
+    s_mr = make_float2((float)mean, rsqrtf((float)var + 1e-5f));
+  }
+  __syncthreads();
+  const float mean = s_mr.x, rstd = s_mr.y;
+  // ---- q | k | v = folded-GroupNorm 1x1 conv: 6 tiles of 32 pixels x 32 channels, K = 64; wave w takes tiles w and w + 4
+  for (int t = wave; t < 6; t += 4) {
+    const int nt = t % 3, mt = t / 3;                            // nt: 0 q, 1 k, 2 v
+    const int nrow = nt * hd + h * 32 + d;                       // this lane's weight row (output channel)
+    typedef float f32x16l __attribute__((ext_vector_type(16)));
+    f32x16l acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      float av[16], wv[16];
+      const float* ap = ht + (mt * 32 + d) * 68 + kc * 32 + 16 * half;
+      const float* wp = qa.W + (long long)nrow * 64 + kc * 32 + 16 * half;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 x = *reinterpret_cast<const float4*>(ap + 4 * j), w = *reinterpret_cast<const float4*>(wp + 4 * j);
+        av[4 * j] = x.x; av[4 * j + 1] = x.y; av[4 * j + 2] = x.z; av[4 * j + 3] = x.w;
+        wv[4 * j] = w.x; wv[4 * j + 1] = w.y; wv[4 * j + 2] = w.z; wv[4 * j + 3] = w.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wv[j], acc, 0, 0, 0);
+    }
+    float* dst = nt == 0 ? sq : (nt == 1 ? sk : sv);
+    const float bv = qa.bias ? qa.bias[nrow] : 0.f;
+    const float gs = qa.gn_s[nrow], gb = qa.gn_b1[nrow];         // a 1x1 conv: the folded-GroupNorm tables are the same for every pixel
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = acc[r] * rstd;
+      v += bv;
+      v += gb - (mean * rstd) * gs;
+      dst[p * 32 + d] = v;
+    }
+  }
+  __syncthreads();
+  // ---- from here on: linattn_lds4_kernel
+  const int kd = tid & 31, kg = tid >> 5;
+  float m = -INFINITY;
+  for (int i = kg; i < a.n; i += 8) m = fmaxf(m, sk[i * 32 + kd]);
+  kred[kg][kd] = m;
+  __syncthreads();
+  float kmax = kred[0][kd];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) kmax = fmaxf(kmax, kred[g][kd]);
+  __syncthreads();
+  float ps = 0.f;
+  for (int i = kg; i < a.n; i += 8) { const float e = expf(sk[i * 32 + kd] - kmax); sk[i * 32 + kd] = e; ps += e; }
+  kred[kg][kd] = ps;
+  {
+    const int qi = tid >> 2, part = tid & 3;
+    if (qi < a.n) {
+      float* qp = sq + qi * 32 + part * 8;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = qp[j];
+      float qm = v[0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) qm = fmaxf(qm, v[j]);
+      qm = fmaxf(qm, __shfl_xor(qm, 1)); qm = fmaxf(qm, __shfl_xor(qm, 2));
+      float qsum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = expf(v[j] - qm); qsum += v[j]; }
+      qsum += __shfl_xor(qsum, 1); qsum += __shfl_xor(qsum, 2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qp[j] = v[j] / qsum * a.scale;
+    }
+  }
+  __syncthreads();
+  float ksum = kred[0][d];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) ksum += kred[g][d];
+  const float kinv = 1.0f / ksum;
+  const int per = (a.n + 3) / 4, i_lo = wave * per, i_hi = min(a.n, i_lo + per);
+  float c[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) c[e] = 0.f;
+  for (int i = i_lo; i < i_hi; ++i) {
+    const float kv = sk[i * 32 + d] * kinv;
+    const float* vrow = sv + i * 32 + half * 16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) c[e] = fmaf(kv, vrow[e], c[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) pctx[wave][d][half * 16 + e] = c[e];
+  __syncthreads();
+  float col[32];
+#pragma unroll
+  for (int dd = 0; dd < 32; ++dd) col[dd] = ((pctx[0][dd][d] + pctx[1][dd][d]) + pctx[2][dd][d]) + pctx[3][dd][d];
+  for (int i = i_lo + half; i < i_hi; i += 2) {
+    const float* qrow = sq + i * 32;
+    float o = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) o = fmaf(col[dd], qrow[dd], o);
+    a.out[((long long)i * a.B + b) * a.ldo + h * 32 + d] = o;
+  }
+}
+
 // softmax attention core (unet_model.py:141-148), n <= 64: one wave per (sample, head); lane = query i
 __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   __shared__ float sk[32][65], sv[32][65];
@@ -1168,6 +1311,28 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
   return nullptr;
 }
 
+bool qkv_linattn_fusable(const Plan& plan, int i) {
+  if (getenv("SBM_NO_QKV_FUSE") || i + 1 >= (int)plan.ops.size()) return false;
+  const Op& a = plan.ops[i]; const Op& b = plan.ops[i + 1];
+  if (a.kind != OP_GEMM || b.kind != OP_LINATTN || a.chain || b.chain) return false;
+  const GemmOp& g = a.g; const AttnOp& t = b.at;
+  if (g.Hout * g.Wout != 64 || g.KH != 1 || g.KW != 1 || g.Kp != 64 || !g.gn || g.has2 || g.has_res || g.act != ACT_NONE || g.a_ext || g.out_nchw) return false;
+  if (g.up != 1 || g.stride != 1 || g.w_pix_stride || g.bias_pix_stride || g.stat_off >= 0) return false;
+  if (t.dh != 32 || t.qkv.off != g.out.off || t.qkv.H * t.qkv.W != 64 || g.out.C != 3 * t.heads * 32 || (g.a.ld & 3)) return false;
+  return true;
+}
+
+const char* launch_qkv_linattn(const DevPlan& dp, int i, hipStream_t st) {
+  const Plan& plan = *dp.plan; const GemmOp& g = plan.ops[i].g; const AttnOp& t = plan.ops[i + 1].at;
+  QkvAttnArgs q{};
+  q.a = make_attn_args(t, dp.ws);
+  q.A = dp.ws + g.a.off; q.lda = g.a.ld; q.W = dp.prm + g.w_off; q.bias = g.bias_off >= 0 ? dp.prm + g.bias_off : nullptr;
+  q.gn_part = reinterpret_cast<const float2*>(dp.ws + g.gn_part_off); q.gn_nparts = g.gn_nparts; q.gn_inv = g.gn_inv_count;
+  q.gn_s = dp.prm + g.gn_s_off; q.gn_b1 = dp.prm + g.gn_b1_off; q.Npad = g.Npad;
+  SBM_KLAUNCH(linattn_qkv_kernel, dim3(t.B * t.heads), dim3(256), 0, st, q);
+  return nullptr;
+}
+
 const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops) {
   const Plan& plan = *dp.plan;
   if (plan.time_off >= 0 && t_dev && t_dev != dp.ws + plan.time_off)
@@ -1179,6 +1344,12 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
     int n = 1;
     const char* e;
     if (skipped(i)) { ++i; continue; }
+    if (plan.ops[i].fuse_next) {                    // to_qkv + LinearAttention core as one kernel
+      e = launch_qkv_linattn(dp, i, st);
+      if (e) return e;
+      i += 2;
+      continue;
+    }
     if (plan.ops[i].chain) {                        // a maximal run of chain ops is ONE launch
       while (i + n < (int)plan.ops.size() && plan.ops[i + n].chain && !skipped(i + n)) ++n;
       e = launch_chain(dp, i, n, st);

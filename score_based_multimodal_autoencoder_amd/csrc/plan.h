@@ -138,6 +138,7 @@ struct Op {
   std::string name;       // reference layer this op implements (for profiles and error messages)
   double flops = 0;       // 2*MAC this op issues (padding taps skipped, channel padding included)
   double flops_dense = 0; // GEMM ops: 2*MAC in the dense convention (zero-padding taps counted), the roofline numerator
+  int fuse_next = 0;      // 1 (set at model creation): this to_qkv GEMM and the LinearAttention core behind it run as one kernel
   int time_path = 0;      // 1: depends on the time input only (sinusoid, time MLP, per-block condition GEMM): the sampler tabulates it
   int chain = 0;          // 1: runs inside the XCD-resident chain kernel (low-resolution ops; GEMM tile 32x32) -- chain.hip
   GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf; Gn32Op gn; AttnQkvOp aq;
