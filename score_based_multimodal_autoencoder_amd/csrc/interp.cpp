@@ -222,6 +222,15 @@ void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const 
       } break;
       case OP_NCHW_TO_PBC: {
         const CvtOp& c = op.cv; const View& o = c.out;
+        if (c.rowpack) {
+          for (int y0 = 0; y0 < o.H; ++y0) for (int b = 0; b < c.B; ++b) for (int k = 0; k < o.ld; ++k) {
+            const int xs = k / c.Cpad, ch = k % c.Cpad, y = y0 - c.pad_y, x = xs - c.pad_x;
+            float v = 0.f;
+            if (xs < c.Wo && ch < c.C && y >= 0 && y < c.Hn && x >= 0 && x < c.Wn) v = in[(((int64_t)b * c.C + ch) * c.Hn + y) * c.Wn + x];
+            ws[o.off + ((int64_t)y0 * c.B + b) * o.ld + k] = v;
+          }
+          break;
+        }
         for (int p = 0; p < o.H * o.W; ++p) for (int b = 0; b < c.B; ++b) for (int ch = 0; ch < o.C; ++ch) {
           int y = p / o.W - c.pad_y, x = p % o.W - c.pad_x;
           float v = 0.f;

@@ -1119,7 +1119,8 @@ __global__ __launch_bounds__(256) void attn_qkv_kernel(const AttnQkvArgs a) {
     }
 }
 
-__global__ void nchw_to_pbc_kernel(const float* in, float* out, int B, int C, int Hn, int Wn, int pad_y, int pad_x, int Ho, int Wo, int ld, int Cv) {
+// rowpack: element (y, x, c) goes to row y, channel x*Cv + c of a [Ho][B][ld] tensor (init_conv's row-packed input)
+__global__ void nchw_to_pbc_kernel(const float* in, float* out, int B, int C, int Hn, int Wn, int pad_y, int pad_x, int Ho, int Wo, int ld, int Cv, int rowpack) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)Ho * Wo * B * Cv;
   if (idx >= total) return;
@@ -1127,7 +1128,8 @@ __global__ void nchw_to_pbc_kernel(const float* in, float* out, int B, int C, in
   const int y = p / Wo - pad_y, x = p % Wo - pad_x;
   float v = 0.f;
   if (c < C && y >= 0 && y < Hn && x >= 0 && x < Wn) v = in[(((long long)b * C + c) * Hn + y) * Wn + x];
-  out[((long long)p * B + b) * ld + c] = v;
+  if (rowpack) out[((long long)(p / Wo) * B + b) * ld + (p % Wo) * Cv + c] = v;
+  else out[((long long)p * B + b) * ld + c] = v;
 }
 
 struct BilArgs { const float* in; float* out; int B, Hi, Wi, Ho, Wo, C, ldi, ldo, scale; };
@@ -1277,8 +1279,10 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       SBM_KLAUNCH(sinus_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, st, ws + plan.time_off, prm + o.freq_off, ws + o.out_off, o.B, o.dim, o.ld, o.cos_first);
     } break;
     case OP_NCHW_TO_PBC: {
-      const CvtOp& o = op.cv; const long long n = (long long)o.out.H * o.out.W * o.B * o.out.C;
-      SBM_KLAUNCH(nchw_to_pbc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ext_in, ws + o.out.off, o.B, o.C, o.Hn, o.Wn, o.pad_y, o.pad_x, o.out.H, o.out.W, o.out.ld, o.out.C);
+      const CvtOp& o = op.cv;
+      const int Ho = o.out.H, Wo = o.rowpack ? o.Wo : o.out.W, Cv = o.rowpack ? o.Cpad : o.out.C;
+      const long long n = (long long)Ho * Wo * o.B * Cv;
+      SBM_KLAUNCH(nchw_to_pbc_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ext_in, ws + o.out.off, o.B, o.C, o.Hn, o.Wn, o.pad_y, o.pad_x, Ho, Wo, o.out.ld, Cv, o.rowpack);
     } break;
     case OP_BILINEAR: {
       const BilinearOp& o = op.bl; BilArgs a{};

@@ -685,11 +685,51 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       plan->flops_dense += 2.0 * B * cin * d.td; plan->flops_dense_gemm += 2.0 * B * cin * d.td; plan->flops_dense_cond += 2.0 * B * cin * d.td;
     };
 
-    // init conv 7x7
-    Builder::ConvSpec ic; ic.name = "init_conv"; ic.a = xin; ic.cm = ChanMap::identity(cfg.channels); ic.cin_true = cfg.channels;
-    ic.kh = ic.kw = 7; ic.pad = 3; ic.w = b.T("init_conv.weight", (int64_t)d.init_dim * cfg.channels * 49); ic.bias = b.T("init_conv.bias", d.init_dim);
-    ic.cout = d.init_dim; ic.Hout = Hp; ic.Wout = Wp;
-    View x = b.emit_conv(ic).out;
+    // init conv 7x7.  With a handful of input channels a tap is 8 floats of a 32-float K chunk (3/4 of the MFMA work would
+    // multiply padding), so the input is stored row-packed -- one "pixel" per image ROW with Wp*8 channels -- and the
+    // horizontal window moves into per-output-pixel weights: 7 row taps x Wp*8/32 chunks instead of 49 taps x 1 chunk.
+    View x;
+    const int rowK = round_up(Wp * 8, 32);
+    const bool rowpack = cfg.channels <= 8 && !std::getenv("SBM_NO_ROWPACK") &&
+                         (int64_t)Hp * Wp * 7 * round_up(pad8(d.init_dim), 32) * rowK * 4 <= (16LL << 20);
+    if (rowpack) {
+      Op& cv = plan->ops[0];                                   // the input conversion emitted above
+      View rows; rows.H = Hp; rows.W = 1; rows.C = Wp * 8; rows.ld = rowK;
+      b.free_act(xin);
+      rows.off = b.ws_alloc((int64_t)Hp * B * rows.ld);
+      cv.cv.out = rows; cv.cv.rowpack = 1; cv.cv.Wo = Wp; cv.cv.Cpad = 8;
+      xin = rows;
+      const float* w = b.T("init_conv.weight", (int64_t)d.init_dim * cfg.channels * 49); const float* bi = b.T("init_conv.bias", d.init_dim);
+      const int P = Hp * Wp, cout = d.init_dim;
+      x = b.new_act(Hp, Wp, cout);
+      Op& op = b.push(OP_GEMM, "init_conv (row-packed)");
+      GemmOp& g = op.g; g.B = B; g.Hout = Hp; g.Wout = Wp; g.a = rows; g.a_rows = 1; g.KH = 7; g.KW = 1; g.stride = 1; g.pad = 3;
+      g.N = cout; g.Npad = round_up(pad8(cout), 32); g.Kp = rowK; g.out = x;
+      std::vector<float> wp((size_t)P * 7 * g.Npad * g.Kp, 0.f), bp(g.Npad, 0.f);
+      for (int pp = 0; pp < P; ++pp) {
+        const int ox = pp % Wp;
+        for (int ky = 0; ky < 7; ++ky) for (int n = 0; n < cout; ++n) for (int xs = 0; xs < Wp; ++xs) {
+          const int kx = xs - ox + 3;
+          if (kx < 0 || kx >= 7) continue;
+          for (int c = 0; c < cfg.channels; ++c)
+            wp[(((size_t)pp * 7 + ky) * g.Npad + n) * g.Kp + xs * 8 + c] = w[(((size_t)n * cfg.channels + c) * 7 + ky) * 7 + kx];
+        }
+      }
+      for (int n = 0; n < cout; ++n) bp[n] = bi[n];
+      g.w_off = b.add_params(wp); g.w_pix_stride = (int64_t)7 * g.Npad * g.Kp; g.bias_off = b.add_params(bp);
+      Builder::choose_tile(B, P, pad8(cout), &g.BM, &g.BN);
+      const double dense = 2.0 * B * cout * ((double)P * 49 * cfg.channels);
+      plan->flops_dense += dense; plan->flops_dense_gemm += dense; op.flops_dense = dense;
+      double rows_valid = 0;
+      for (int oy = 0; oy < Hp; ++oy) for (int ky = 0; ky < 7; ++ky) rows_valid += (oy - 3 + ky >= 0 && oy - 3 + ky < Hp) ? Wp : 0;
+      op.flops = 2.0 * B * g.Npad * rows_valid * g.Kp;
+      plan->flops_exec += op.flops;
+    } else {
+      Builder::ConvSpec ic; ic.name = "init_conv"; ic.a = xin; ic.cm = ChanMap::identity(cfg.channels); ic.cin_true = cfg.channels;
+      ic.kh = ic.kw = 7; ic.pad = 3; ic.w = b.T("init_conv.weight", (int64_t)d.init_dim * cfg.channels * 49); ic.bias = b.T("init_conv.bias", d.init_dim);
+      ic.cout = d.init_dim; ic.Hout = Hp; ic.Wout = Wp;
+      x = b.emit_conv(ic).out;
+    }
     b.free_act(xin);
 
     // down path.  Level i>=1 writes its skip tensor straight into the second half of the concat
@@ -815,7 +855,9 @@ void finalize_gemm_tables(Plan* plan) {
       const int first = (int)(desc.size() / 4);
       int n1 = 0;
       for (int ky = 0; ky < g.KH; ++ky) for (int kx = 0; kx < g.KW; ++kx) {
-        const int q = g.a_bcast ? 0 : tap_source_pixel(oy, ox, ky, kx, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W);
+        int q;
+        if (g.a_rows) { const int iy = oy * g.stride - g.pad + ky; q = (iy >= 0 && iy < g.a.H) ? iy : -1; }
+        else q = g.a_bcast ? 0 : tap_source_pixel(oy, ox, ky, kx, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W);
         if (q < 0) continue;
         for (int kc = 0; kc < g.Kp; kc += 32) {
           desc.push_back(chk((int64_t)q * g.B * g.a.ld + kc));

@@ -54,6 +54,8 @@ struct GemmOp {
   int up = 1;             // nearest-neighbour upsample folded into the read (source pixel = q / up)
   int KH = 1, KW = 1, stride = 1, pad = 0, transposed = 0;
   int a_bcast = 0;        // 1: source is a single-pixel tensor read by every output pixel
+  int a_rows = 0;         // 1: source "pixels" are image ROWS (CvtOp::rowpack): tap ky of output pixel (oy, ox) reads row oy - pad + ky,
+                          //    the horizontal window lives in the per-output-pixel weights (w_pix_stride)
   int64_t w_off = 0;      // params: [tap][Npad][Kp]
   int64_t w_pix_stride = 0;  // params: extra offset per output pixel (z_lin), else 0
   // GroupNorm(1,C) applied on load to source 1
@@ -127,7 +129,11 @@ struct Gn32Op { int B = 0; View in, out; int groups = 32; int silu = 0; int64_t 
 // qkv channels per head h: [q | k | v] at h*3*chh (unet_openai.py:333,351-352); out channels h*chh
 struct AttnQkvOp { int B = 0; View qkv, out; int heads = 1, chh = 0; float scale = 0.f; };
 
-struct CvtOp { int B = 0; int C = 0; int Hn = 0, Wn = 0; int pad_y = 0, pad_x = 0; View out; };
+struct CvtOp {
+  int B = 0; int C = 0; int Hn = 0, Wn = 0; int pad_y = 0, pad_x = 0; View out;
+  int rowpack = 0;        // 1: `out` is a view of H "pixels" (image rows) with W*Cpad channels each: element (y, x, c) at channel x*Cpad + c;
+  int Wo = 0, Cpad = 0;   //    Wo columns of Cpad channels per row (init_conv's row-packed input)
+};
 
 struct BilinearOp { int B = 0; int scale = 2; View in, out; };
 
