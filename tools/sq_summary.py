@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc passes over tools/traffic_probe.py into per-kernel averages per launch (JSON on stdout).
+
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT \
+              SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace -d gpurun_out/pmc_sq1 -o t --output-format csv -- python3 tools/traffic_probe.py
+    rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -d gpurun_out/pmc_sq2 -o t --output-format csv -- python3 tools/traffic_probe.py
+    python3 tools/sq_summary.py gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 > profiles/r01_sq_counters.json
+
+Derived: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) -- the share of the launch during which
+a SIMD's matrix pipe is executing (v_mfma_f32_32x32x2_f32 holds it 64 cycles) -- and the split of the waves' resident time into
+parked (s_waitcnt / barrier), issue-stalled and issuing (SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES).
+"""
+import collections, csv, glob, json, os, sys
+
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+for d in sys.argv[1:]:
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            if not name.startswith("sbm::"):
+                continue
+            a = acc[name][row["Counter_Name"]]
+            a[0] += float(row["Counter_Value"]); a[1] += 1
+out = {}
+for name, ctrs in sorted(acc.items()):
+    e = {k: round(t / n, 1) for k, (t, n) in sorted(ctrs.items())}
+    e["launches"] = max(n for _, n in ctrs.values())
+    wc = e.get("SQ_WAVE_CYCLES")
+    if wc:
+        for k, lab in (("SQ_WAIT_ANY", "waves_parked_frac"), ("SQ_WAIT_INST_ANY", "waves_issue_stalled_frac"), ("SQ_ACTIVE_INST_ANY", "waves_issuing_frac")):
+            if k in e:
+                e[lab] = round(e[k] / wc, 4)
+    if "GRBM_GUI_ACTIVE" in e and "SQ_VALU_MFMA_BUSY_CYCLES" in e and e["GRBM_GUI_ACTIVE"] > 0:
+        e["mfma_busy_frac"] = round(e["SQ_VALU_MFMA_BUSY_CYCLES"] / (e["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+    if "SQ_LDS_IDX_ACTIVE" in e and e["SQ_LDS_IDX_ACTIVE"] > 0 and "SQ_LDS_BANK_CONFLICT" in e:
+        e["lds_bank_conflict_frac"] = round(e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"], 4)
+    out[name] = e
+print(json.dumps(out, indent=1))
