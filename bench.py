@@ -138,6 +138,12 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
+    from score_based_multimodal_autoencoder_amd import _lib as _L
+    if not os.path.exists(_L.LIB_PATH):          # the in-tree library normally travels with the tree; compile it (hipcc, gfx950) if it did not
+        if local == 0:
+            _L.build(verbose=True)
+        if world > 1:
+            torch.distributed.barrier()
     log(f"rank {rank}/{world}: building models")
     score, decs = build_models(device)
     sde = VPSDE(BETA[0], BETA[1], N_SDE)
