@@ -173,6 +173,32 @@ int sbm_debug_gemm_stamps(sbm_model* m, const float* in_dev, float* out_dev, int
 int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps,
                           double* ms_per_op, double* flops_per_op, int n_ops);
 
+/* ---- evaluation statistics right behind the path: pytorch_fid/fid_score.py on device features, fp64 ----
+ * The Inception network is not part of this library (its weights are not available offline): the entry points start from the
+ * (n, dims) feature rows the reference collects in `pred_arr` (fid_score.py:127-153, 163-184). */
+
+/* sum[d] += sum_i feats[i][d], gram[d][e] += sum_i feats[i][d] * feats[i][e], both fp64 on the device, feats fp32 (row pitch ld).
+ * One call per batch of features; a rank accumulates its shard, the two buffers are then summed over ranks (one all-reduce of
+ * dims + dims^2 doubles) -- what replaces growing `pred_arr` and np.mean / np.cov over it (fid_score.py:248-250, 273-279). */
+int sbm_fid_accumulate(const float* feats_dev, long n, int dims, long ld, double* sum_dev, double* gram_dev, void* stream);
+
+/* mu = sum / n, sigma = (gram - n mu mu^T) / (n - 1): np.mean(act, axis=0), np.cov(act, rowvar=False) (fid_score.py:249-250) */
+int sbm_fid_finalize_stats(const double* sum_dev, const double* gram_dev, long n, int dims, double* mu_dev, double* sigma_dev, void* stream);
+
+/* calculate_frechet_distance(mu1, sigma1, mu2, sigma2, eps) (fid_score.py:187-240) on device fp64 operands.
+ * Tr sqrtm(sigma1 sigma2) is taken as Tr sqrtm(S sigma2 S), S = sqrtm(sigma1), both roots by coupled Newton-Schulz iterations of
+ * fp64 MFMA GEMMs stopped when the trace is stationary (at most max_iters each, 0 = default 60); if a root is not finite the
+ * iteration is repeated with eps added to both diagonals, as the reference does (:224-229).
+ * work_dev: sbm_fid_work_doubles(dims) doubles of device scratch.  out_host[5] (HOST memory) = {d^2, Tr sqrtm, iterations of the
+ * first root, of the second root, 1 if eps was used}.  Synchronises the stream. */
+long sbm_fid_work_doubles(int dims);
+int sbm_fid_frechet(const double* mu1_dev, const double* sigma1_dev, const double* mu2_dev, const double* sigma2_dev, int dims, double eps,
+                    int max_iters, double* work_dev, double* out_host, void* stream);
+
+/* test hook: C[M][N] = alpha * At^T B + beta * C + diag * I with At [K][M], B [K][N] row-major fp64 (the GEMM the entries above use);
+ * K < 0: the first operand is A [M][-K] row-major instead (C = alpha * A B + ...) */
+int sbm_debug_dgemm_tn(const double* At_dev, const double* B_dev, double* C_dev, int M, int N, int K, double alpha, double beta, double diag, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,10 @@ using namespace sbm;
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
 static int fail_hip(const char* what, hipError_t e) { g_err = std::string(what) + ": " + hipGetErrorString(e); return 2; }
+namespace sbm {
+int api_fail(const std::string& m) { return fail(m); }                       // for the other translation units of the library (fid.hip)
+int api_fail_hip(const char* what, hipError_t e) { return fail_hip(what, e); }
+}
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_hip(#x, e_); } while (0)
 
 struct sbm_model {

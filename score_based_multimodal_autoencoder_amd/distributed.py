@@ -74,6 +74,14 @@ def sample_sharded(sample_fn, global_batch, group=None, gather=True):
     return all_gather_cat(local, group)
 
 
+def all_reduce_sum(t, group=None):
+    """In-place sum of `t` over the ranks (identity for a single process): the FID stage's exchange of feature sums
+    (fid_score.ActivationStatistics.all_reduce; SURVEY 8(e): 2048 + 2048^2 values)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def langevin_norm_allreduce(norm_sums, group=None):
     """Opt-in exact mode for the corrector: its step size uses BATCH-mean norms (sde_helper2.py:97-99),
     so a sharded run matches the single-device reference only if the two sums are all-reduced."""

@@ -432,3 +432,46 @@ def encoder_cases():
 
 if __name__ == "__main__" and "enc" in sys.argv[1:]:
     encoder_cases()
+
+
+# ---------------------------------------------------------------------------------------------
+# FID stage: the reference's own pytorch_fid.fid_score.calculate_frechet_distance, and np.mean / np.cov exactly as
+# calculate_activation_statistics applies them (fid_score.py:249-250), on synthetic "activation" rows.  The Inception network is
+# never run (torchvision and its weights are not available offline): inert stubs stand in for the imports it would need.
+def fid_features(seed, n, dims, shift):
+    """Non-negative, correlated rows like pooled ReLU activations (float32 as the network would give them)."""
+    rng = np.random.default_rng(seed)
+    mix = rng.standard_normal((dims, dims)) * (0.3 / np.sqrt(dims / 48.0))
+    return np.maximum(rng.standard_normal((n, dims)) @ mix + shift, 0.0).astype(np.float32)
+
+
+def fid_cases():
+    for name in ("torchvision.transforms", "PIL", "PIL.Image"):
+        sys.modules.setdefault(name, _Inert(name))
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    inc = types.ModuleType("torchvision.models.inception")          # base classes the (unused) Inception wrappers derive from
+    for cls in ("InceptionA", "InceptionC", "InceptionE"):
+        setattr(inc, cls, type(cls, (torch.nn.Module,), {}))
+    sys.modules["torchvision.models.inception"] = inc
+    sys.modules["torchvision.models"].inception = inc
+    from pytorch_fid import fid_score as F  # noqa: E402  (reference)
+    out = {}
+    for tag, n, dims in (("full", 300, 48), ("singular", 30, 48), ("wide", 200, 160)):
+        a1, a2 = fid_features(11, n, dims, 0.20), fid_features(12, n, dims, 0.27)
+        pred1, pred2 = np.empty((n, dims)), np.empty((n, dims))       # float64 holders, as get_activations fills them (:127, :147)
+        pred1[:] = a1; pred2[:] = a2
+        m1, s1 = np.mean(pred1, axis=0), np.cov(pred1, rowvar=False)
+        m2, s2 = np.mean(pred2, axis=0), np.cov(pred2, rowvar=False)
+        fid = F.calculate_frechet_distance(m1, s1, m2, s2)
+        out[f"{tag}.act1"], out[f"{tag}.act2"] = a1, a2
+        out[f"{tag}.mu1"], out[f"{tag}.mu2"] = m1, m2
+        if dims <= 48:                                               # (the covariances of the wide case are implied by act + fid)
+            out[f"{tag}.sigma1"], out[f"{tag}.sigma2"] = s1, s2
+        out[f"{tag}.fid"] = np.float64(fid)
+        print(tag, n, dims, "fid", fid)
+    save("fid.npz", **out)
+
+
+if __name__ == "__main__" and "fid" in sys.argv[1:]:
+    fid_cases()
