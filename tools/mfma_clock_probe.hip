@@ -36,6 +36,22 @@ __global__ __launch_bounds__(256) void probe16(float* out, unsigned long long* s
   out[blockIdx.x * 256 + threadIdx.x] = s;
   if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
+typedef double f64x4v __attribute__((ext_vector_type(4)));
+template <int nacc>
+__global__ __launch_bounds__(256) void probe64(float* out, unsigned long long* stamps, int iters) {
+  f64x4v a[8];
+  for (int k = 0; k < 8; ++k) a[k] = f64x4v{0, 0, 0, 0};
+  double x = threadIdx.x * 1e-3, y = blockIdx.x * 1e-3 + 1.0;
+  unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < nacc; ++k) a[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a[k], 0, 0, 0);
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  double s = 0; for (int k = 0; k < nacc; ++k) s += a[k][0] + a[k][1] + a[k][2] + a[k][3];
+  out[blockIdx.x * 256 + threadIdx.x] = (float)s;
+  if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
 int main() {
   float* out; unsigned long long* st;
   hipMalloc(&out, 4096 * 256 * 4); hipMalloc(&st, 4096 * 16);
@@ -64,6 +80,21 @@ int main() {
       std::vector<unsigned long long> h(2 * blocks); hipMemcpy(h.data(), st, 16 * blocks, hipMemcpyDeviceToHost);
       double mf = (double)blocks * 4 * iters * nacc, flop = mf * 2048.0;
       if (rep == 2) printf("16x16x4 nacc=%d blocks=%5d  %9.1f us  %7.1f TF/s  cyc/mfma/wave=%6.1f  clock %6.0f MHz\n", nacc, blocks, ms * 1e3, flop / (ms * 1e-3) / 1e12,
+             (double)h[0] / ((double)iters * nacc), (double)h[0] / (double)h[1] * 100.0);
+    }
+  }
+  for (int nacc : {1, 4, 8}) for (int blocks : {256, 1024}) {
+    int iters = 8192;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0);
+      if (nacc == 1) hipLaunchKernelGGL(probe64<1>, dim3(blocks), dim3(256), 0, 0, out, st, iters);
+      else if (nacc == 4) hipLaunchKernelGGL(probe64<4>, dim3(blocks), dim3(256), 0, 0, out, st, iters);
+      else hipLaunchKernelGGL(probe64<8>, dim3(blocks), dim3(256), 0, 0, out, st, iters);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      std::vector<unsigned long long> h(2 * blocks); hipMemcpy(h.data(), st, 16 * blocks, hipMemcpyDeviceToHost);
+      double mf = (double)blocks * 4 * iters * nacc, flop = mf * 2048.0;
+      if (rep == 2) printf("f64 16x16x4 nacc=%d blocks=%5d  %9.1f us  %7.1f TF/s  cyc/mfma/wave=%6.1f  clock %6.0f MHz\n", nacc, blocks, ms * 1e3, flop / (ms * 1e-3) / 1e12,
              (double)h[0] / ((double)iters * nacc), (double)h[0] / (double)h[1] * 100.0);
     }
   }
