@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/sbmae.h"
@@ -49,17 +50,21 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, double*
 // MFMA tiles (lane l of the MFMA: A[row l & 15][k = l >> 4], B[k = l >> 4][col l & 15], D[row (l >> 4) + 4 r][col l & 15]).
 // K chunks of 16 go global -> registers -> LDS, the next chunk's loads in flight under the current chunk's 64 MFMAs per wave
 // (an fp64 MFMA holds the pipe 64 cycles: the kernel is matrix-pipe bound at 8 bytes per clock per CU of operand traffic).
-template <typename TIn, bool AT>
-__global__ __launch_bounds__(256) void dgemm_kernel(const TIn* __restrict__ At, long lda, const TIn* __restrict__ Bm, long ldb,
+// TN = 64: a 128 x 64 tile (wave: 4 x 2 MFMA tiles, 64 accumulator registers), 57 KB of LDS and <= 256 registers per wave, so that
+// TWO workgroups share a CU -- the fp64 MFMA issues once per ~140 cycles per wave (tools/mfma_clock_probe), and only a second
+// wave on the SIMD fills the gaps.
+template <typename TIn, bool AT, int TN>
+__global__ __launch_bounds__(256, TN == 64 ? 2 : 1) void dgemm_kernel(const TIn* __restrict__ At, long lda, const TIn* __restrict__ Bm, long ldb,
                                                        double* __restrict__ C, long ldc, int M, int N, int K, double alpha, double beta, double diag) {
   __shared__ __attribute__((aligned(16))) double As[2][DG_BK * DG_LD];
-  __shared__ __attribute__((aligned(16))) double Bs[2][DG_BK * DG_LD];
+  constexpr int LDB = TN + 16, EB = TN / 16, NU = TN / 32;      // B tile row stride, columns per loader thread, MFMA tiles per wave in N
+  __shared__ __attribute__((aligned(16))) double Bs[2][DG_BK * LDB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * DG_T, n0 = blockIdx.x * DG_T;
-  const int kr = tid >> 4, c8 = (tid & 15) * 8;                // loader: row kr of the chunk, 8 consecutive columns
+  const int m0 = blockIdx.y * DG_T, n0 = blockIdx.x * TN;
+  const int kr = tid >> 4, c8 = (tid & 15) * 8, cb = (tid & 15) * EB;   // loader: row kr of the chunk, 8 (A) / EB (B) consecutive columns
   const int am = tid >> 1, ak = (tid & 1) * 8;                 // !AT loader: row am of the tile, 8 consecutive k
   const bool vec_a = (lda % (16 / (long)sizeof(TIn))) == 0 && (reinterpret_cast<uintptr_t>(At) & 15) == 0 && (AT ? m0 + DG_T <= M : m0 + am < M);
-  const bool vec_b = (ldb % (16 / (long)sizeof(TIn))) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0 && n0 + DG_T <= N;
+  const bool vec_b = EB == 8 && (ldb % (16 / (long)sizeof(TIn))) == 0 && (reinterpret_cast<uintptr_t>(Bm) & 15) == 0 && n0 + TN <= N;
   double ra[8], rb[8];
   auto gload = [&](int k0) {
     const int k = k0 + kr;
@@ -79,13 +84,13 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const TIn* __restrict__ At, 
     if (k < K && vec_b) load8<TIn>(Bm + (long)k * ldb + n0 + c8, rb);
     else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) rb[e] = (k < K && n0 + c8 + e < N) ? (double)Bm[(long)k * ldb + n0 + c8 + e] : 0.0;
+      for (int e = 0; e < EB; ++e) rb[e] = (k < K && n0 + cb + e < N) ? (double)Bm[(long)k * ldb + n0 + cb + e] : 0.0;
     }
   };
   auto lstore = [&](int buf) {
-    double2* pb = reinterpret_cast<double2*>(&Bs[buf][kr * DG_LD + c8]);
+    double2* pb = reinterpret_cast<double2*>(&Bs[buf][kr * LDB + cb]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pb[i] = make_double2(rb[2 * i], rb[2 * i + 1]);
+    for (int i = 0; i < EB / 2; ++i) pb[i] = make_double2(rb[2 * i], rb[2 * i + 1]);
     if constexpr (AT) {
       double2* pa = reinterpret_cast<double2*>(&As[buf][kr * DG_LD + c8]);
 #pragma unroll
@@ -95,11 +100,11 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const TIn* __restrict__ At, 
       for (int e = 0; e < 8; ++e) As[buf][(ak + e) * DG_LD + am] = ra[e];        // transposed into the k-major tile
     }
   };
-  f64x4 acc[4][4];
+  f64x4 acc[4][NU];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < NU; ++u) acc[t][u] = f64x4{0.0, 0.0, 0.0, 0.0};
   gload(0);
   lstore(0);
   __syncthreads();
@@ -111,14 +116,16 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const TIn* __restrict__ At, 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const double* ap = &As[buf][(4 * kk + fk) * DG_LD + wm * 64 + fr];
-      const double* bp = &Bs[buf][(4 * kk + fk) * DG_LD + wn * 64 + fr];
-      double a[4], b[4];
+      const double* bp = &Bs[buf][(4 * kk + fk) * LDB + wn * (TN / 2) + fr];
+      double a[4], b[NU];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) { a[t] = ap[16 * t]; b[t] = bp[16 * t]; }
+      for (int t = 0; t < 4; ++t) a[t] = ap[16 * t];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) b[u] = bp[16 * u];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[u], acc[t][u], 0, 0, 0);
+        for (int u = 0; u < NU; ++u) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[u], acc[t][u], 0, 0, 0);
     }
     if (more) lstore(buf ^ 1);
     __syncthreads();
@@ -126,10 +133,10 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const TIn* __restrict__ At, 
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + t * 16 + fk + 4 * r, col = n0 + wn * 64 + u * 16 + fr;
+        const int row = m0 + wm * 64 + t * 16 + fk + 4 * r, col = n0 + wn * (TN / 2) + u * 16 + fr;
         if (row < M && col < N) {
           double v = alpha * acc[t][u][r];
           if (beta != 0.0) v += beta * C[(long)row * ldc + col];
@@ -141,12 +148,16 @@ __global__ __launch_bounds__(256) void dgemm_kernel(const TIn* __restrict__ At, 
 
 template <typename TIn>
 void dgemm_tn(const TIn* At, long lda, const TIn* B, long ldb, double* C, long ldc, int M, int N, int K, double alpha, double beta, double diag, hipStream_t st) {
-  dim3 grid((N + DG_T - 1) / DG_T, (M + DG_T - 1) / DG_T);
-  hipLaunchKernelGGL((dgemm_kernel<TIn, true>), grid, dim3(256), 0, st, At, lda, B, ldb, C, ldc, M, N, K, alpha, beta, diag);
+  static const int tn = std::getenv("SBM_DGEMM_TN") ? std::atoi(std::getenv("SBM_DGEMM_TN")) : 64;
+  dim3 grid((N + tn - 1) / tn, (M + DG_T - 1) / DG_T);
+  if (tn == 64) hipLaunchKernelGGL((dgemm_kernel<TIn, true, 64>), grid, dim3(256), 0, st, At, lda, B, ldb, C, ldc, M, N, K, alpha, beta, diag);
+  else hipLaunchKernelGGL((dgemm_kernel<TIn, true, 128>), grid, dim3(256), 0, st, At, lda, B, ldb, C, ldc, M, N, K, alpha, beta, diag);
 }
 void dgemm_nn(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int M, int N, int K, double alpha, double beta, double diag, hipStream_t st) {
-  dim3 grid((N + DG_T - 1) / DG_T, (M + DG_T - 1) / DG_T);
-  hipLaunchKernelGGL((dgemm_kernel<double, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, diag);
+  static const int tn = std::getenv("SBM_DGEMM_TN") ? std::atoi(std::getenv("SBM_DGEMM_TN")) : 64;
+  dim3 grid((N + tn - 1) / tn, (M + DG_T - 1) / DG_T);
+  if (tn == 64) hipLaunchKernelGGL((dgemm_kernel<double, false, 64>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, diag);
+  else hipLaunchKernelGGL((dgemm_kernel<double, false, 128>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, diag);
 }
 
 // A <- (A + A^T) / 2 (square, in place: thread (i, j), i < j, owns the pair)
