@@ -135,6 +135,12 @@ int sbm_langevin_fixed_step(const float* x, const float* score, const float* noi
 int sbm_renoise_observed(const sbm_sde_cfg* sde, const float* x, const float* z_obs, const float* t, float* x_out, unsigned obs_mask,
                          int B, int n_mod, int per_mod, void* stream);
 
+/* One ancestral step of the DiffuseVAE refiner's DDPM loop (eval_lat_celeba_hq_all.py:107-118), on (B, chw) rows:
+ *   x_out = sqrt_recip_alpha_t * (x - beta_t * eps / sqrt(1 - alphabar_t)) + sigma_t * z,  sigma_t = sqrt(posterior_variance_t), 0 at t = 0.
+ * eps = sm_model(cat[x, vae_out], t).  noise == NULL: z from the in-kernel Philox stream keyed by (seed, global sample, step). */
+int sbm_ddpm_step(const float* x, const float* eps, const float* noise, float* x_out, float sqrt_recip_alpha, float beta, float sqrt_one_minus_abar,
+                  float sigma, int B, long chw, uint64_t seed, uint64_t sample_offset, int step, void* stream);
+
 /* out[b, :] = scale * N(0,1) from the same Philox stream (prior draw: SDE.prior_sampling, sde_helper2.py:364,415,457) */
 int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_t sample_offset, int step, int draw,
                     float scale, void* stream);

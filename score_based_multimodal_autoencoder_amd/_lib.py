@@ -22,7 +22,7 @@ EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "s
            "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step",
            "sbm_fill_normal", "sbm_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_stamps",
-           "sbm_fid_accumulate", "sbm_fid_finalize_stats", "sbm_fid_work_doubles", "sbm_fid_frechet", "sbm_debug_dgemm_tn"]
+           "sbm_ddpm_step", "sbm_fid_accumulate", "sbm_fid_finalize_stats", "sbm_fid_work_doubles", "sbm_fid_frechet", "sbm_debug_dgemm_tn"]
 
 
 class SdeCfg(ctypes.Structure):
@@ -101,6 +101,7 @@ def lib():
         L.sbm_debug_chain_sync.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), i]
         L.sbm_debug_chain_stamps.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_uint64)]
         L.sbm_debug_profile_ops.argtypes = [vp, vp, vp, vp, i, ctypes.POINTER(dbl), ctypes.POINTER(dbl), i]
+        L.sbm_ddpm_step.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i, ctypes.c_long, u64, u64, i, vp]
         L.sbm_fid_accumulate.argtypes = [vp, ctypes.c_long, i, ctypes.c_long, vp, vp, vp]
         L.sbm_fid_finalize_stats.argtypes = [vp, vp, ctypes.c_long, i, vp, vp, vp]
         L.sbm_fid_work_doubles.restype = ctypes.c_long

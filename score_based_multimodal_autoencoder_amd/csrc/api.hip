@@ -496,6 +496,16 @@ int sbm_langevin_fixed_step(const float* x, const float* score, const float* noi
   return 0;
 }
 
+int sbm_ddpm_step(const float* x, const float* eps, const float* noise, float* x_out, float sqrt_recip_alpha, float beta, float sqrt_one_minus_abar,
+                  float sigma, int B, long chw, uint64_t seed, uint64_t sample_offset, int step, void* stream) {
+  if (!x || !eps || !x_out || B <= 0 || chw <= 0 || chw % 4 || chw > 0x7fffffffL || !(sqrt_one_minus_abar > 0.f)) return fail("sbm_ddpm_step: bad arguments (chw must be a positive multiple of 4)");
+  StepArgs s{};
+  s.x = x; s.score = eps; s.noise = noise; s.x_out = x_out; s.B = B; s.CHW = (int)chw; s.seed = seed; s.sample_offset = sample_offset; s.step_base = step; s.draw = 0;
+  launch_ddpm_step(s, sqrt_recip_alpha, beta, sqrt_one_minus_abar, sigma, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int sbm_renoise_observed(const sbm_sde_cfg* sde, const float* x, const float* z_obs, const float* t, float* x_out, unsigned obs_mask, int B, int n_mod,
                          int per_mod, void* stream) {
   if (!sde || !x || !z_obs || !t || !x_out || B <= 0 || n_mod <= 0 || n_mod > 32 || per_mod <= 0 || per_mod % 4) return fail("sbm_renoise_observed: bad arguments");

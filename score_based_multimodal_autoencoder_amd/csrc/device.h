@@ -134,6 +134,7 @@ struct StepArgs {
 };
 
 void launch_em_step(const StepArgs& a, hipStream_t st);
+void launch_ddpm_step(const StepArgs& a, float sqrt_recip_alpha, float beta, float sqrt_one_minus_abar, float sigma, hipStream_t st);
 void launch_langevin_step(const StepArgs& a, hipStream_t st);   // norms + update (two kernels)
 void launch_fill_time(float* t_out, const float* timesteps, const int* step_counter, int B, hipStream_t st);
 void launch_advance(int* step_counter, hipStream_t st);

@@ -161,6 +161,28 @@ void launch_axpy_noise(const StepArgs& a, float ca, float cb, float sdiv, unsign
   hipLaunchKernelGGL(axpy_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, ca, cb, sdiv, mod_mask, per_mod);
 }
 
+// One ancestral step of the DiffuseVAE refiner's DDPM loop (eval_lat_celeba_hq_all.py:107-118):
+//   mean = sqrt_recip_alpha_t * (x - beta_t * eps / sqrt(1 - alphabar_t));  x_out = mean + sigma_t * z   (sigma_t = 0 at t = 0: no draw)
+__global__ __launch_bounds__(256) void ddpm_step_kernel(const StepArgs a, float r, float beta, float s1m, float sigma) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q4 = a.CHW >> 2;
+  if (idx >= (long long)a.B * q4) return;
+  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
+  const float4 x = *reinterpret_cast<const float4*>(a.x + (long long)b * a.CHW + e);
+  const float4 s = *reinterpret_cast<const float4*>(a.score + (long long)b * a.CHW + e);
+  float4 o;
+  o.x = r * (x.x - (beta * s.x) / s1m); o.y = r * (x.y - (beta * s.y) / s1m); o.z = r * (x.z - (beta * s.z) / s1m); o.w = r * (x.w - (beta * s.w) / s1m);
+  if (sigma != 0.f) {
+    const float4 z = load_noise4(a, b, e, (unsigned)a.step_base);
+    o.x += sigma * z.x; o.y += sigma * z.y; o.z += sigma * z.z; o.w += sigma * z.w;
+  }
+  *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
+}
+void launch_ddpm_step(const StepArgs& a, float r, float beta, float s1m, float sigma, hipStream_t st) {
+  const long long n = (long long)a.B * (a.CHW >> 2);
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, r, beta, s1m, sigma);
+}
+
 // Re-noising of the observed modalities in the conditional loop (train_poly_unet_cont.py:356-364,
 // train_lat_celebhq_unet_cont2.py:293-301): x_out[:, c] = mean_coef(t) * z_obs[:, c] + std(t) * z_obs[:, c] for observed c
 // (the reference multiplies std by z itself, not by fresh noise -- reproduced knowingly), x[:, c] otherwise.

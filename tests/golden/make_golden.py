@@ -475,3 +475,48 @@ def fid_cases():
 
 if __name__ == "__main__" and "fid" in sys.argv[1:]:
     fid_cases()
+
+
+# ---------------------------------------------------------------------------------------------
+# DiffuseVAE refiner loop: the reference's own eval_lat_celeba_hq_all.evaluate_diff_vae (1000 ancestral DDPM steps,
+# hard-coded) around a toy unet_openai.UNetModel(6 -> 3) whose output is scaled by 0.1 (filler weights do not make an epsilon
+# predictor; unscaled, 1000 steps overflow).  Noise draws are injected and logged.
+class _Scaled(torch.nn.Module):
+    def __init__(self, m, s):
+        super().__init__()
+        self.m, self.s = m, s
+
+    def forward(self, x, t):
+        return self.s * self.m(x, t)
+
+
+def ddpm_cases():
+    for n in ("torchvision.transforms", "torchvision.utils", "torchvision.datasets", "matplotlib", "matplotlib.pyplot", "pytorch_fid",
+              "pytorch_fid.fid_score", "PIL", "PIL.Image", "celeba_hq_mask_dataset", "mopoe_model", "mmplus_model_cel", "sklearn", "sklearn.metrics"):
+        sys.modules.setdefault(n, _Inert(n))
+    for n in ("jax", "jax.numpy", "torchvision", "torchvision.models"):
+        sys.modules[n] = _Inert(n)
+    cvd = os.environ.get("CUDA_VISIBLE_DEVICES")
+    import eval_lat_celeba_hq_all as E  # noqa: E402  (reference script module; sets CUDA_VISIBLE_DEVICES at import)
+    if cvd is None:
+        os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+    from unet_openai import UNetModel
+    kw = dict(in_channels=6, model_channels=32, out_channels=3, num_res_blocks=1, attention_resolutions=(2,), channel_mult=(1, 2))
+    m = UNetModel(kw["in_channels"], kw["model_channels"], kw["out_channels"], kw["num_res_blocks"], kw["attention_resolutions"], 0.1,
+                  kw["channel_mult"], num_heads=2).eval()
+    synth.fill_module_(m)
+    B, hw = 2, 8
+    vae_out = (inp("ddpm.vae_out", (B, 3, hw, hw), 0.25) + 0.5).astype(np.float32)
+    spy = _Spy(_Scaled(m, 0.1), (0, 1, 500, 999))
+    with _Noise(0xF4) as nz:
+        y = E.evaluate_diff_vae(torch.from_numpy(vae_out), spy, "cpu")
+    assert len(nz.log) == 1000 and nz.log[0][0] == "normal"          # the initial sample + one draw per step with t > 0
+    out = {"vae_out": vae_out, "y": y.numpy(), "seed": np.asarray([0xF4, len(nz.log)])}
+    for k, v in spy.seen.items():
+        out[f"xin{k}"] = v
+    print("ddpm: model calls", spy.calls, "draws", len(nz.log), "|y| max", float(y.abs().max()))
+    save("ddpm_refiner.npz", **out)
+
+
+if __name__ == "__main__" and "ddpm" in sys.argv[1:]:
+    ddpm_cases()
