@@ -10,16 +10,13 @@ import torch
 
 def schedule(timesteps=1000):
     """-> dict of float32 arrays [timesteps]: betas, sqrt_recip_alphas, sqrt_one_minus_alphas_cumprod, sqrt_posterior_variance."""
-    betas = torch.linspace(0.0001, 0.02, timesteps)                                       # :62-65
-    alphas = 1. - betas
-    alphas_cumprod = torch.cumprod(alphas, axis=0)
-    alphas_cumprod_prev = torch.nn.functional.pad(alphas_cumprod[:-1], (1, 0), value=1.0)
-    sqrt_recip_alphas = torch.sqrt(1.0 / alphas)
-    sqrt_one_minus_alphas_cumprod = torch.sqrt(1. - alphas_cumprod)
-    posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)       # :93
-    return dict(betas=betas.numpy(), sqrt_recip_alphas=sqrt_recip_alphas.numpy(),
-                sqrt_one_minus_alphas_cumprod=sqrt_one_minus_alphas_cumprod.numpy(),
-                sqrt_posterior_variance=torch.sqrt(posterior_variance).numpy())
+    beta = torch.linspace(0.0001, 0.02, timesteps)                                        # :62-65
+    abar = torch.cumprod(1. - beta, axis=0)                                               # alphas_cumprod (:83-84)
+    abar_prev = torch.nn.functional.pad(abar[:-1], (1, 0), value=1.0)                     # :85
+    pv = beta * (1. - abar_prev) / (1. - abar)                                            # posterior_variance (:93)
+    return dict(betas=beta.numpy(), sqrt_recip_alphas=torch.sqrt(1.0 / (1. - beta)).numpy(),          # :86
+                sqrt_one_minus_alphas_cumprod=torch.sqrt(1. - abar).numpy(),                           # :90
+                sqrt_posterior_variance=torch.sqrt(pv).numpy())
 
 
 def evaluate_diff_vae(vae_out, eps_fn, draw, timesteps=1000):

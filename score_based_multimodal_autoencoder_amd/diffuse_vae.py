@@ -34,14 +34,13 @@ def evaluate_diff_vae(vae_out, sm_model, device, timesteps=1000, *, noise=None, 
     chw = vae_out[0].numel()
     if chw % 4:
         raise ValueError("C*H*W must be a multiple of 4")
-    betas = linear_beta_schedule(timesteps=timesteps)
-    alphas = 1. - betas
-    alphas_cumprod = torch.cumprod(alphas, axis=0)
-    alphas_cumprod_prev = F.pad(alphas_cumprod[:-1], (1, 0), value=1.0)
-    sqrt_recip_alphas = torch.sqrt(1.0 / alphas)
-    sqrt_one_minus_alphas_cumprod = torch.sqrt(1. - alphas_cumprod)
-    posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
-    sigma = torch.sqrt(posterior_variance)
+    # the reference's schedule (eval_lat_celeba_hq_all.py:80-93), same float32 torch expressions so the coefficients are bit-equal
+    beta = linear_beta_schedule(timesteps)
+    abar = torch.cumprod(1. - beta, axis=0)
+    abar_prev = F.pad(abar[:-1], (1, 0), value=1.0)
+    recip = torch.sqrt(1.0 / (1. - beta))                         # sqrt_recip_alphas
+    s1m = torch.sqrt(1. - abar)                                   # sqrt_one_minus_alphas_cumprod
+    sigma = torch.sqrt(beta * (1. - abar_prev) / (1. - abar))     # sqrt(posterior_variance)
     L = _lib.lib()
     st = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     if sample0 is not None:
@@ -60,7 +59,7 @@ def evaluate_diff_vae(vae_out, sm_model, device, timesteps=1000, *, noise=None, 
         if t > 0 and noise is not None:
             z = noise(t).to(device=vae_out.device, dtype=torch.float32).contiguous()
         _lib.check(L.sbm_ddpm_step(sample.data_ptr(), eps.data_ptr(), z.data_ptr() if z is not None else None, nxt.data_ptr(),
-                                   float(sqrt_recip_alphas[t]), float(betas[t]), float(sqrt_one_minus_alphas_cumprod[t]),
+                                   float(recip[t]), float(beta[t]), float(s1m[t]),
                                    float(sigma[t]) if t > 0 else 0.0, B, chw, seed, sample_offset, t, st()))
         sample, nxt = nxt, sample
     return (sample + 1) / 2
