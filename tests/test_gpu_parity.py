@@ -389,6 +389,39 @@ def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
     assert torch.isfinite(outs["16"]).all()
 
 
+def test_full_size_sampling_run_is_path_and_shard_independent(pkg):
+    """BASELINE config 2 at full size (B = 256, 1000 reverse-SDE steps, in-kernel Philox noise): the samples do not depend on
+    WHICH kernels carry the low-resolution levels (XCD-resident chain vs one launch per layer) beyond float32 reassociation, nor
+    on how the batch is split (two shards of 128 keyed by their global sample offset = the unsharded run, bit for bit per path)."""
+    import os
+    from score_based_multimodal_autoencoder_amd.sde_helper2 import VPSDE, uncond_sampler
+    m = _unet(pkg, "P5")
+    sde = VPSDE(0.1, 5.0, 1000)
+    x0 = torch.empty(256, 5, 8, 8, device="cuda")
+    pkg["lib"].check(pkg["lib"].lib().sbm_fill_normal(x0.data_ptr(), 5 * 64, 256, 1234, 0, 0, 255, 1.0, None))
+    outs = {}
+    for pix in ("0", "16"):
+        os.environ["SBM_CHAIN_PIX"] = pix
+        try:
+            m.release_engines()
+            outs[pix] = uncond_sampler((256, 5, 8, 8), m, "cuda", sde, x0=x0, seed=7, sample_offset=0).clone()
+            if pix == "16":
+                again = uncond_sampler((256, 5, 8, 8), m, "cuda", sde, x0=x0, seed=7, sample_offset=0)
+                assert torch.equal(again, outs[pix]), "the run must be deterministic"
+                halves = [uncond_sampler((128, 5, 8, 8), m, "cuda", sde, x0=x0[o:o + 128], seed=7, sample_offset=o) for o in (0, 128)]
+                # a 128-sample engine takes the per-layer kernels for some levels (fewer tiles than XCDs are allowed, but the
+                # tile GEMMs differ): same trajectory up to reassociation
+                d = float((torch.cat(halves) - outs[pix]).abs().max())
+                assert d <= 5e-3 * float(outs[pix].abs().max()), d
+        finally:
+            os.environ.pop("SBM_CHAIN_PIX", None)
+            m.release_engines()
+    assert torch.isfinite(outs["16"]).all()
+    scale = float(outs["0"].abs().max())
+    # 1000 steps of a contracting VP reverse SDE: per-step differences of ~1e-6 do not grow
+    assert float((outs["0"] - outs["16"]).abs().max()) <= 5e-3 * scale
+
+
 # ------------------------------------------------------------------------------------------------
 # encoders (SURVEY 8(f1): the conditional loop's source of observed latents)
 @pytest.mark.parametrize("name", ["ResVAE", "ResAE"])
