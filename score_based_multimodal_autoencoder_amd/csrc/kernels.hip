@@ -795,7 +795,8 @@ struct QkvAttnArgs {
 
 __global__ __launch_bounds__(256) void linattn_qkv_kernel(const QkvAttnArgs qa) {
   const AttnArgs& a = qa.a;
-  __shared__ __attribute__((aligned(16))) float sq[64 * 32], sk[64 * 32], sv[64 * 32];      // [pixel][d]
+  constexpr int QLD = 33;                                         // q rows are padded: the output MFMA reads q[pixel = lane][k] (a column)
+  __shared__ __attribute__((aligned(16))) float sq[64 * QLD], sk[64 * 32], sv[64 * 32];     // [pixel][d]
   __shared__ __attribute__((aligned(16))) float ht[64 * 68];                                 // block input tile [pixel][64 + 4]
   __shared__ float pctx[4][32][33];
   __shared__ float kred[8][32];
@@ -857,7 +858,7 @@ __global__ __launch_bounds__(256) void linattn_qkv_kernel(const QkvAttnArgs qa) 
       float v = acc[r] * rstd;
       v += bv;
       v += gb - (mean * rstd) * gs;
-      dst[p * 32 + d] = v;
+      dst[p * (nt == 0 ? QLD : 32) + d] = v;
     }
   }
   __syncthreads();
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(256) void linattn_qkv_kernel(const QkvAttnArgs qa) 
   {
     const int qi = tid >> 2, part = tid & 3;
     if (qi < a.n) {
-      float* qp = sq + qi * 32 + part * 8;
+      float* qp = sq + qi * QLD + part * 8;
       float v[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = qp[j];
@@ -894,32 +895,45 @@ __global__ __launch_bounds__(256) void linattn_qkv_kernel(const QkvAttnArgs qa) 
     }
   }
   __syncthreads();
-  float ksum = kred[0][d];
+  // ---- context[d][e] = sum_px softmax_k[px][d] v[px][e] and out[px][e] = sum_d softmax_q[px][d] context[d][e] on the matrix pipe
+  //      (v_mfma_f32_32x32x2_f32; lane (i = lane & 31, half): A[i][k = 2 s + half], B[k = 2 s + half][j = lane & 31]).  Each wave
+  //      contracts 16 of the 64 pixels (8 MFMAs); the four partial contexts meet in LDS, scaled by 1 / sum_k.
+  typedef float f32x16l __attribute__((ext_vector_type(16)));
+  {
+    f32x16l cacc;
 #pragma unroll
-  for (int g = 1; g < 8; ++g) ksum += kred[g][d];
-  const float kinv = 1.0f / ksum;
-  const int per = (a.n + 3) / 4, i_lo = wave * per, i_hi = min(a.n, i_lo + per);
-  float c[16];
+    for (int r = 0; r < 16; ++r) cacc[r] = 0.f;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) c[e] = 0.f;
-  for (int i = i_lo; i < i_hi; ++i) {
-    const float kv = sk[i * 32 + d] * kinv;
-    const float* vrow = sv + i * 32 + half * 16;
+    for (int s2 = 0; s2 < 8; ++s2) {
+      const int px = wave * 16 + 2 * s2 + half;
+      cacc = __builtin_amdgcn_mfma_f32_32x32x2f32(sk[px * 32 + d], sv[px * 32 + d], cacc, 0, 0, 0);
+    }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) c[e] = fmaf(kv, vrow[e], c[e]);
+    for (int r = 0; r < 16; ++r) pctx[wave][(r & 3) + 8 * (r >> 2) + 4 * half][d] = cacc[r];
   }
-#pragma unroll
-  for (int e = 0; e < 16; ++e) pctx[wave][d][half * 16 + e] = c[e];
   __syncthreads();
-  float col[32];
+  float* ctxs = sk;                                              // [d][32]: k is dead once every wave has its partial context
+  for (int idx = tid; idx < 32 * 32; idx += 256) {
+    const int dd = idx >> 5, e = idx & 31;
+    float ks = kred[0][dd];
 #pragma unroll
-  for (int dd = 0; dd < 32; ++dd) col[dd] = ((pctx[0][dd][d] + pctx[1][dd][d]) + pctx[2][dd][d]) + pctx[3][dd][d];
-  for (int i = i_lo + half; i < i_hi; i += 2) {
-    const float* qrow = sq + i * 32;
-    float o = 0.f;
+    for (int g = 1; g < 8; ++g) ks += kred[g][dd];
+    ctxs[idx] = (((pctx[0][dd][e] + pctx[1][dd][e]) + pctx[2][dd][e]) + pctx[3][dd][e]) * (1.0f / ks);
+  }
+  __syncthreads();
+  if (wave < 2) {                                                // two 32-pixel tiles of the output, K = 32
+    f32x16l oacc;
 #pragma unroll
-    for (int dd = 0; dd < 32; ++dd) o = fmaf(col[dd], qrow[dd], o);
-    a.out[((long long)i * a.B + b) * a.ldo + h * 32 + d] = o;
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    const float* qa_ = sq + (wave * 32 + d) * QLD + half;
+    const float* cb = ctxs + half * 32 + d;
+#pragma unroll
+    for (int s2 = 0; s2 < 16; ++s2) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa_[2 * s2], cb[2 * s2 * 32], oacc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int px = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      a.out[((long long)px * a.B + b) * a.ldo + h * 32 + d] = oacc[r];
+    }
   }
 }
 
