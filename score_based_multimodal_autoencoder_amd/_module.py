@@ -81,3 +81,12 @@ def as_f32_cuda(t, what):
     if t.dtype != torch.float32:
         t = t.to(torch.float32)
     return t.contiguous()
+
+
+def fresh_seed(seed=None):
+    """Philox key of one sampler call.  `None` draws a fresh 64-bit key from torch's default generator, so successive calls get
+    independent in-loop noise (as the reference's per-call `torch.randn_like`, sde_helper2.py:47,96), `torch.manual_seed`
+    reproduces a run, and the generator state advances."""
+    if seed is None:
+        return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+    return int(seed) & 0xFFFFFFFFFFFFFFFF

@@ -289,10 +289,10 @@ extern "C" {
 int sbm_fid_accumulate(const float* feats, long n, int dims, long ld, double* sum, double* gram, void* stream) {
   if (!feats || !sum || !gram || n < 0 || dims <= 0 || ld < dims) return api_fail("sbm_fid_accumulate: bad arguments");
   if (n == 0) return 0;
+  if (n > 0x7fffffffL) return api_fail("sbm_fid_accumulate: more than 2^31 rows per call");      // before the first launch: no partial update
   hipStream_t st = (hipStream_t)stream;
   const int yb = (int)(n < 4096 ? (n + 63) / 64 : 64);
   hipLaunchKernelGGL(colsum_kernel, dim3((dims + 63) / 64, yb > 0 ? yb : 1), dim3(256), 0, st, feats, ld, n, dims, sum);
-  if (n > 0x7fffffffL) return api_fail("sbm_fid_accumulate: more than 2^31 rows per call");
   dgemm_tn<float>(feats, ld, feats, ld, gram, dims, dims, dims, (int)n, 1.0, 1.0, 0.0, st);       // gram += X^T X
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : api_fail_hip("sbm_fid_accumulate", e);

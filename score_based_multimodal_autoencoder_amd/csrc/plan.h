@@ -1,5 +1,5 @@
 // plan.h -- op descriptors shared by the host plan builder (plan.cpp), the device launcher
-// (kernels.hip) and the test-only host interpreter (interp.cpp).
+// (kernels.hip) and the test-only host interpreter (tests/interp.cpp).
 //
 // Data layout in HBM ("PBC"): every internal activation is [P][B][ld] fp32, P = H*W pixel planes,
 // B samples per plane, channel-contiguous rows of `ld` floats (ld % 4 == 0, channels padded with

@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from ._module import as_f32_cuda
+from ._module import as_f32_cuda, fresh_seed
 
 
 def linear_beta_schedule(timesteps):
@@ -24,9 +24,11 @@ def linear_beta_schedule(timesteps):
 
 
 @torch.no_grad()
-def evaluate_diff_vae(vae_out, sm_model, device, timesteps=1000, *, noise=None, sample0=None, seed=0, sample_offset=0):
+def evaluate_diff_vae(vae_out, sm_model, device, timesteps=1000, *, noise=None, sample0=None, seed=None, sample_offset=0):
     """Keyword-only extras (defaults = reference behaviour with in-kernel noise): `noise(t)` -> injected N(0,1) tensor for step t
-    (parity tests), `sample0` initial sample, `seed` / `sample_offset` Philox key and global index of row 0 (sharded runs)."""
+    (parity tests), `sample0` initial sample, `seed` / `sample_offset` Philox key (None: fresh per call from torch's default generator) and global index of row 0
+    (sharded runs)."""
+    seed = fresh_seed(seed)
     if hasattr(sm_model, "eval"):
         sm_model.eval()
     vae_out = as_f32_cuda(vae_out, "vae_out")

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._module import as_f32_cuda
+from ._module import as_f32_cuda, fresh_seed
 
 
 def _mask(n_mod, predicted):
@@ -84,8 +84,7 @@ def annealed_langevin(score_model, z, sigmas=None, er=None, c=None, iter_num=Non
     for m in ers:
         groups.setdefault((ers[m], cs[m]), []).append(m)
     sig = default_sigmas() if sigmas is None else np.asarray(torch.as_tensor(sigmas).detach().cpu().numpy(), np.float64)
-    if seed is None:
-        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    seed = fresh_seed(seed)
     single = len(groups) == 1
     buf = torch.empty_like(z) if single else None
     with torch.no_grad():
@@ -114,8 +113,7 @@ def mlp_langevin(score_model, z, n_comp=50, lr1=0.03, lr2=0.001, schedule=False,
     iteration applies a second update of size 1 with the same score (fid_upd10.py:336-339); noise then has n_comp+1 draws."""
     z = as_f32_cuda(z, "z").clone()
     B = z.shape[0]
-    if seed is None:
-        seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+    seed = fresh_seed(seed)
     buf = torch.empty_like(z)
     with torch.no_grad():
         for i in range(n_comp):

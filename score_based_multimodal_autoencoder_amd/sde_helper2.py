@@ -14,7 +14,8 @@ Additions, all keyword-only and defaulted so reference call sites keep working:
            'pc' (predictor then corrector, train_poly_unet_cont.uncond_sampler)
     noise  injected draws (parity tests): tensor [(N * draws_per_step), B, C, H, W] in execution order
     x0     initial state instead of sde.prior_sampling(shape)
-    seed / sample_offset   Philox key and global index of row 0 (results do not depend on sharding)
+    seed / sample_offset   Philox key (None: a fresh key per call from torch's default generator) and global index of
+           row 0 (pc=False results do not depend on sharding; pc=True see `exact_sharded_norms`)
 """
 import ctypes
 import math
@@ -23,7 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._module import as_f32_cuda
+from ._module import as_f32_cuda, fresh_seed
 
 
 class SDE:
@@ -270,8 +271,7 @@ def uncond_sampler(sample_shape, model, device, sde, eps=1e-3, probability_flow=
             else:
                 eng = model._engine_for(B, x.shape[2], x.shape[3])
             cfg = sde._cfg(target_snr=target_snr, probability_flow=probability_flow)
-            if seed is None:
-                seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+            seed = fresh_seed(seed)
             scfg = _lib.SamplerCfg(int(bool(pc)), int(n_steps), 0 if order == "cp" else 1, int(bool(use_graph)),
                                    int(seed), int(sample_offset))
             alphas = _alphas_dev(sde, device) if pc else None

@@ -1,4 +1,4 @@
-// interp.cpp -- TEST-ONLY scalar host interpreter of a Plan.
+// tests/interp.cpp -- TEST-ONLY scalar host interpreter of a Plan.
 //
 // Built with g++ into libsbmae_planref.so (never linked into the product library).  It executes the
 // op descriptors of plan.h with plain loops on host memory, in the same PBC layout and with the same

@@ -1,4 +1,4 @@
-"""ctypes wrapper of the TEST-ONLY host plan interpreter (csrc/interp.cpp -> libsbmae_planref.so).
+"""ctypes wrapper of the TEST-ONLY host plan interpreter (tests/interp.cpp -> tests/libsbmae_planref.so).
 
 Used by the CPU suite to check the C++ plan builder / weight packer (shared with the product
 library) against the oracle and the golden fixtures without a GPU.  Never imported by the product.
@@ -11,15 +11,16 @@ import numpy as np
 
 CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                     "score_based_multimodal_autoencoder_amd", "csrc")
-LIB = os.path.join(CSRC, "libsbmae_planref.so")
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "libsbmae_planref.so")
 
 
 def build():
-    srcs = [os.path.join(CSRC, f) for f in ("plan.cpp", "interp.cpp")]
+    srcs = [os.path.join(CSRC, "plan.cpp"), os.path.join(HERE, "interp.cpp")]
     deps = srcs + [os.path.join(CSRC, "plan.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + srcs)
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", CSRC, "-o", LIB] + srcs)
     return LIB
 
 

@@ -1,5 +1,5 @@
 """Host logic of the product: the C++ plan builder / weight packer (csrc/plan.cpp), executed by the
-test-only scalar interpreter (csrc/interp.cpp), against the golden fixtures and the oracle."""
+test-only scalar interpreter (tests/interp.cpp), against the golden fixtures and the oracle."""
 import numpy as np
 import pytest
 
