@@ -122,6 +122,17 @@ int sbm_langevin_step(const sbm_sde_cfg* sde, const float* x, const float* score
                       const float* alphas, float* x_out, float* mean_out, float* norms_scratch, int B, int CHW,
                       uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream);
 
+/* The same iteration in two halves, for a batch sharded over ranks (SURVEY 8(e) "exact mode"): the step size uses the MEAN of the
+ * per-sample norms over the whole batch (sde_helper2.py:97-99), so between the halves the caller all-reduces two numbers.
+ *   sbm_langevin_norms:  sums_out[0] = sum_b ||score_b||, sums_out[1] = sum_b ||noise_b|| over THIS shard's B rows, in fp64 (exact for
+ *                        batches of this size, hence independent of the split); norms_scratch: device 2*B floats
+ *   sbm_langevin_update: the update with norm_sums = those sums added over all shards and B_global = the global batch size. */
+int sbm_langevin_norms(const float* score, const float* noise, float* norms_scratch, double* sums_out, int B, int CHW, uint64_t seed,
+                       uint64_t sample_offset, int step, int draw, void* stream);
+int sbm_langevin_update(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t, const float* alphas,
+                        float* x_out, float* mean_out, const double* norm_sums, long B_global, int B, int CHW, uint64_t seed,
+                        uint64_t sample_offset, int step, int draw, void* stream);
+
 /* Fixed-step Langevin update of the alternative samplers, on the joint state (B, n_mod, per_mod):
  *   x_out[:, m] = x[:, m] + a * (score[:, m] / score_div) + b * noise[:, m]  for modalities m with bit m of mod_mask set, x[:, m] otherwise.
  *   annealed Langevin (fid_upd10.gen_ae :97, eval_lat_celeba_hq_all.evaluate :258-275): a = alpha, score_div = sigma_i, b = c*sqrt(2*alpha)
@@ -174,6 +185,7 @@ long sbm_debug_workspace_floats(const sbm_model* m);
 int sbm_debug_read_workspace(sbm_model* m, long off, long n, float* host);
 int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap);
 int sbm_debug_chain_sync(sbm_model* m, unsigned* out, int n_words);
+int sbm_debug_chain_ctl(sbm_model* m, unsigned spin_limit, int skip_arrive);   /* barrier poll limit (0 = default); 1 = force a barrier time-out */
 int sbm_debug_chain_stamps(sbm_model* m, int first, int count, unsigned long long* out_host);
 int sbm_debug_gemm_stamps(sbm_model* m, const float* in_dev, float* out_dev, int i, unsigned long long* stamps_host);
 int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps,

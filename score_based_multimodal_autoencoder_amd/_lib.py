@@ -19,9 +19,9 @@ OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "n
                  "attn_qkv", "chain_kernel", "avgpool"]
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
-           "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step",
+           "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step", "sbm_langevin_norms", "sbm_langevin_update",
            "sbm_fill_normal", "sbm_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
-           "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_stamps",
+           "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_ctl", "sbm_debug_chain_stamps",
            "sbm_ddpm_step", "sbm_fid_accumulate", "sbm_fid_finalize_stats", "sbm_fid_work_doubles", "sbm_fid_frechet", "sbm_debug_dgemm_tn"]
 
 
@@ -85,6 +85,8 @@ def lib():
         L.sbm_model_gemm_flops.argtypes = [vp, ctypes.POINTER(dbl)]
         L.sbm_em_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, vp]
         L.sbm_langevin_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
+        L.sbm_langevin_norms.argtypes = [vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
+        L.sbm_langevin_update.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_long, i, i, u64, u64, i, i, vp]
         L.sbm_langevin_fixed_step.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_uint, i, i, i, u64, u64, i, i,
                                               vp]
         L.sbm_renoise_observed.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, ctypes.c_uint, i, i, i, vp]
@@ -99,6 +101,7 @@ def lib():
         L.sbm_debug_op_name.argtypes = [vp, i, ctypes.c_char_p, i]
         L.sbm_debug_gemm_stamps.argtypes = [vp, vp, vp, i, ctypes.POINTER(ctypes.c_uint64)]
         L.sbm_debug_chain_sync.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), i]
+        L.sbm_debug_chain_ctl.argtypes = [vp, ctypes.c_uint, i]
         L.sbm_debug_chain_stamps.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_uint64)]
         L.sbm_debug_profile_ops.argtypes = [vp, vp, vp, vp, i, ctypes.POINTER(dbl), ctypes.POINTER(dbl), i]
         L.sbm_ddpm_step.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i, ctypes.c_long, u64, u64, i, vp]

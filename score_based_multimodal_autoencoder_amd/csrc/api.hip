@@ -34,6 +34,7 @@ struct sbm_model {
   ChainOp* d_chain_ops = nullptr; // one per op (filled for ops marked op.chain)
   ChainSync* d_chain_sync = nullptr;
   int* d_chain_sched = nullptr;   // unit schedules of the chain GEMMs
+  unsigned* h_abort = nullptr;    // host-mapped word the chain kernel raises when a barrier times out (polled without synchronising)
   const float* aux_persistent = nullptr;   // z_cond used by sbm_sampler_run (sbm_model_set_aux)
   DevPlan dp;
   // sampler scratch (score nets only)
@@ -88,6 +89,17 @@ static SdeParams make_sde(const sbm_sde_cfg& c) {
   return s;
 }
 
+// A chain-kernel barrier that timed out in an EARLIER call (not every workgroup resident -- e.g. the GPU shared with another
+// process) raised the host-mapped flag.  Every entry point that launches the kernel looks at it first, without synchronising:
+// the synchronisation state is reset (in stream order) and the call fails, naming the earlier results as invalid.
+static int chain_prior_abort(sbm_model* m, hipStream_t st, const char* who) {
+  if (!m->h_abort || !__atomic_load_n(m->h_abort, __ATOMIC_RELAXED)) return 0;
+  (void)hipMemsetAsync(m->d_chain_sync, 0, sizeof(ChainSync), st);
+  __atomic_store_n(m->h_abort, 0u, __ATOMIC_RELAXED);
+  return fail(std::string(who) + ": a chain-kernel barrier timed out in an earlier call on this model (not every workgroup was resident?); "
+              "the results of that call are invalid.  The synchronisation state has been reset; repeat the call.");
+}
+
 extern "C" {
 
 const char* sbm_last_error(void) { return g_err.c_str(); }
@@ -111,6 +123,7 @@ void sbm_model_destroy(sbm_model* m) {
   if (m->d_chain_ops) (void)hipFree(m->d_chain_ops);
   if (m->d_chain_sync) (void)hipFree(m->d_chain_sync);
   if (m->d_chain_sched) (void)hipFree(m->d_chain_sched);
+  if (m->h_abort) (void)hipHostFree(m->h_abort);
   if (m->d_score) (void)hipFree(m->d_score);
   if (m->d_norms) (void)hipFree(m->d_norms);
   if (m->d_counter) (void)hipFree(m->d_counter);
@@ -222,7 +235,15 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
       (void)hipGetDevice(&dev);
       (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
       m->dp.chain_ops = m->d_chain_ops; m->dp.chain_sync = m->d_chain_sync;
-      m->dp.chain_grid = cus > 0 && cus < 256 ? cus : 256;      // one workgroup per CU: all of them are resident together
+      // The kernel's barriers need the whole grid resident at once: the grid is (workgroups per CU the occupancy calculator
+      // grants this kernel) x CUs, verified here -- a device that cannot hold it gets an error, never a different numeric path.
+      if (cus <= 0) { sbm_model_destroy(m); return fail("sbm_model_create: cannot read the CU count"); }
+      if (const char* ge = chain_launch_geometry(cus, &m->dp.chain_grid, &m->dp.chain_block)) { std::string msg = ge; sbm_model_destroy(m); return fail("sbm_model_create: " + msg); }
+      if ((e = hipHostMalloc(reinterpret_cast<void**>(&m->h_abort), 64, hipHostMallocMapped)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipHostMalloc(abort flag)", e); }
+      *m->h_abort = 0;
+      unsigned* dev_view = nullptr;
+      if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_view), m->h_abort, 0)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipHostGetDevicePointer", e); }
+      m->dp.chain_ctl.abort_host = dev_view;
     }
   }
   if (kind == SBM_UNET || kind == SBM_UNET_OA) {
@@ -265,6 +286,7 @@ int sbm_model_forward_aux(sbm_model* m, const float* in_dev, const float* t_dev,
 int sbm_model_forward(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, void* stream) {
   if (!m || !in_dev || !out_dev) return fail("sbm_model_forward: bad arguments");
   if (m->plan.needs_time && !t_dev) return fail("sbm_model_forward: this score net needs a time vector");
+  if (int rc = chain_prior_abort(m, (hipStream_t)stream, "sbm_model_forward")) return rc;
   const char* e = run_plan(m->dp, in_dev, t_dev, out_dev, (hipStream_t)stream);
   return e ? fail(std::string("sbm_model_forward: ") + e) : 0;
 }
@@ -327,6 +349,13 @@ int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap) {
   if (!m || i < 0 || i >= (int)m->plan.ops.size() || cap <= 0) return fail("sbm_debug_op_name: bad index");
   std::string s = std::to_string(m->plan.ops[i].kind) + ":" + m->plan.ops[i].name;
   std::strncpy(name, s.c_str(), cap - 1); name[cap - 1] = 0;
+  return 0;
+}
+
+// test knobs of the chain kernel: barrier poll limit (0 = default) and "one workgroup never arrives" (forces the time-out path)
+int sbm_debug_chain_ctl(sbm_model* m, unsigned spin_limit, int skip_arrive) {
+  if (!m) return fail("sbm_debug_chain_ctl: bad arguments");
+  m->dp.chain_ctl.spin_limit = spin_limit; m->dp.chain_ctl.debug_skip = skip_arrive ? 1u : 0u;
   return 0;
 }
 
@@ -485,6 +514,28 @@ int sbm_langevin_step(const sbm_sde_cfg* sde, const float* x, const float* score
   return 0;
 }
 
+int sbm_langevin_norms(const float* score, const float* noise, float* norms_scratch, double* sums_out, int B, int CHW, uint64_t seed,
+                       uint64_t sample_offset, int step, int draw, void* stream) {
+  if (!score || !norms_scratch || !sums_out || B <= 0 || CHW <= 0 || CHW % 4) return fail("sbm_langevin_norms: bad arguments (C*H*W must be a positive multiple of 4)");
+  StepArgs a{};
+  a.score = score; a.noise = noise; a.norms = norms_scratch; a.B = B; a.CHW = CHW; a.seed = seed; a.sample_offset = sample_offset; a.step_base = step; a.draw = draw;
+  launch_langevin_norms(a, sums_out, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sbm_langevin_update(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t, const float* alphas,
+                        float* x_out, float* mean_out, const double* norm_sums, long B_global, int B, int CHW, uint64_t seed, uint64_t sample_offset,
+                        int step, int draw, void* stream) {
+  if (!sde || !x || !score || !t || !x_out || !mean_out || !norm_sums || B <= 0 || B_global < B || CHW <= 0 || CHW % 4) return fail("sbm_langevin_update: bad arguments");
+  if (sde->kind != 2 && !alphas) return fail("sbm_langevin_update: VP/subVP need the alphas table");
+  StepArgs a = step_args(sde, x, score, noise, t, x_out, mean_out, B, CHW, seed, sample_offset, step, draw);
+  a.alphas = alphas; a.norm_sums = norm_sums; a.B_global = B_global;
+  launch_langevin_update(a, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int sbm_langevin_fixed_step(const float* x, const float* score, const float* noise, float* x_out, float a, float b, float score_div, unsigned mod_mask, int B,
                             int n_mod, int per_mod, uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream) {
   if (!x || !score || !x_out || B <= 0 || n_mod <= 0 || n_mod > 32 || per_mod <= 0 || per_mod % 4 || !(score_div != 0.f)) return fail("sbm_langevin_fixed_step: bad arguments");
@@ -579,6 +630,7 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
   if (m->plan.in_C != m->plan.out_C) return fail("sbm_sampler_run: score net must map the state onto itself");
   const SdeParams sp = make_sde(*sde);
   hipStream_t caller = (hipStream_t)stream, st = m->own;
+  if (int rc = chain_prior_abort(m, st, "sbm_sampler_run")) return rc;
   HIPCHK(hipEventRecord(m->ev_in, caller));
   HIPCHK(hipStreamWaitEvent(st, m->ev_in, 0));
   launch_set_counter(m->d_counter, first_step, st);
@@ -586,7 +638,11 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
     sbm_model* m; hipStream_t st; bool armed = false;
     ~TableModeGuard() { if (armed) { (void)hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st); (void)hipStreamSynchronize(st); } }
   } guard{m, st};
-  hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  struct GraphGuard {          // every exit path (HIPCHK returns included) releases the captured step; the stream is drained first
+    hipStream_t st; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+    ~GraphGuard() { if (exec || graph) (void)hipStreamSynchronize(st); if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
+  } gg{st};
+  hipGraph_t& graph = gg.graph; hipGraphExec_t& exec = gg.exec;
   const char* e = nullptr;
   // Every sample of the loop shares the step's time: tabulate the time path (sinusoid, time MLP, per-block condition GEMM)
   // for all N steps once, B steps per pass through the very same ops; the depthwise kernels then index the table by the
@@ -616,13 +672,13 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table);
     hipError_t ce = hipStreamEndCapture(st, &graph);
-    if (e) { if (graph) (void)hipGraphDestroy(graph); return fail(std::string("sbm_sampler_run: ") + e); }
+    if (e) return fail(std::string("sbm_sampler_run: ") + e);
     if (ce != hipSuccess) return fail_hip("hipStreamEndCapture", ce);
     HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
   }
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t0, st));
   for (int i = 0; i < n_run; ++i) {
-    if (exec) { hipError_t le = hipGraphLaunch(exec, st); if (le != hipSuccess) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); return fail_hip("hipGraphLaunch", le); } }
+    if (exec) { hipError_t le = hipGraphLaunch(exec, st); if (le != hipSuccess) return fail_hip("hipGraphLaunch", le); }
     else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table))) return fail(std::string("sbm_sampler_run: ") + e);
   }
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t1, st));
@@ -631,16 +687,12 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
   HIPCHK(hipStreamWaitEvent(caller, m->ev_out, 0));
   if (elapsed_ms || exec) {
     hipError_t se = hipStreamSynchronize(st);
-    if (exec) { (void)hipGraphExecDestroy(exec); (void)hipGraphDestroy(graph); }
     if (se != hipSuccess) return fail_hip("hipStreamSynchronize", se);
     if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, m->ev_t0, m->ev_t1));
-    if (m->d_chain_sync) {                                     // a chain-kernel barrier that timed out invalidates the run: say so, loudly
-      unsigned flag = 0;
-      HIPCHK(hipMemcpy(&flag, &m->d_chain_sync->abort_flag, sizeof(unsigned), hipMemcpyDeviceToHost));
-      if (flag) {
-        (void)hipMemset(m->d_chain_sync, 0, sizeof(ChainSync));
-        return fail("sbm_sampler_run: a chain-kernel barrier timed out (not every workgroup was resident?); results are invalid");
-      }
+    if (m->h_abort && __atomic_load_n(m->h_abort, __ATOMIC_RELAXED)) {    // the stream is idle here: the flag is final for this run
+      (void)hipMemset(m->d_chain_sync, 0, sizeof(ChainSync));
+      __atomic_store_n(m->h_abort, 0u, __ATOMIC_RELAXED);
+      return fail("sbm_sampler_run: a chain-kernel barrier timed out (not every workgroup was resident?); results are invalid");
     }
   }
   HIPCHK(hipGetLastError());

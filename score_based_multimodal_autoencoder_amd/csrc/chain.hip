@@ -17,6 +17,8 @@
 // A barrier that does not complete within ~0.2 s sets ChainSync::abort_flag and every workgroup leaves: the grid always drains.
 #include <hip/hip_ext.h>
 
+#include <cstdlib>
+
 #include "device.h"
 
 namespace sbm {
@@ -68,9 +70,7 @@ DEVINL unsigned ctr_load(unsigned* p) { return __hip_atomic_load(p, __ATOMIC_REL
 DEVINL void ctr_zero(unsigned* p) { (void)__hip_atomic_exchange(p, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 constexpr unsigned SPIN_LIMIT = 1u << 21;
-constexpr int NT = 512, NW = NT / 64;          // threads / waves per workgroup (one workgroup per CU, two waves per SIMD)
 constexpr int A_LD = 36;                       // LDS row stride (floats) of a wave's 32x32 A tile
-constexpr int SMEM_F = NW * 32 * A_LD;         // floats: per-wave A tiles are the largest user (linattn: NW*1120, GEMM reduce: NW*32*33)
 
 // Op descriptors live in LDS (staged once per launch); copying one through readfirstlane puts it in SGPRs.
 template <class T> DEVINL T uniform_copy(const T& src) {
@@ -92,12 +92,23 @@ template <class T> DEVINL T* uniform_ptr(T* p) {
 }
 
 
+// NT threads per workgroup, GROUPS independent sample groups per XCD.  GROUPS = 1: one 512-thread workgroup per CU carries a
+// 32-sample tile per XCD.  GROUPS = 2: two 256-thread workgroups per CU; the XCD's workgroups split into two clusters that
+// carry 16-sample tiles independently of each other, so that one cluster's barrier waits / L2 round trips / reductions are
+// covered by the other's arithmetic (the chain is latency-bound: matrix pipe busy 12 %, waves parked 68 % with GROUPS = 1).
+template <int NT, int GROUPS>
+struct ChainImpl {
+static constexpr int NW = NT / 64;             // waves per workgroup
+static constexpr int TROWS = 32 / GROUPS;      // samples per tile (the MFMA tile stays 32 rows; rows >= TROWS are never stored)
+static constexpr int SMEM_F = NW * 32 * A_LD;  // floats: per-wave A tiles are the largest user (linattn: NW*1120, GEMM reduce: NW*32*33)
+
 struct Ctx {
   int tid, lane, wave;
   int slot, cs;          // this workgroup's index within its cluster, cluster size
   int b0, B;             // first sample of the tile being carried, batch size
   float* smem; float2* mr; unsigned* flag;
   unsigned* bar; unsigned gen; ChainSync* sync;
+  unsigned spin_limit; unsigned* abort_host; bool skip_arrive;
   unsigned long long* tr;   // diagnostics: per-op trace slots of the stamping workgroup (null otherwise)
 };
 #define TR(i) do { if (c.tr && c.tid == 0) c.tr[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -107,7 +118,14 @@ struct Ctx {
 // serial chain of cold misses (descriptor -> weights).
 // The loaded words are folded into a value the caller consumes after the barrier, so the loads are ordinary tracked loads
 // (a load whose destination register the compiler believes dead would land in whatever lives there by then).
-DEVINL unsigned prefetch_next(const ChainOp& nx, const Ctx& c) {
+// a barrier timed out: flag it for every workgroup (device copy) and for the host (host-mapped copy, read by the API without a
+// synchronisation at the entry of the next call on this model)
+static DEVINL void raise_abort(const Ctx& c) {
+  (void)__hip_atomic_exchange(&c.sync->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (c.abort_host) __hip_atomic_store(c.abort_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+static DEVINL unsigned prefetch_next(const ChainOp& nx, const Ctx& c) {
   unsigned sink = 0;
   if (nx.kind != OP_GEMM) return sink;
   const ChainGemm& m = nx.gm;
@@ -134,16 +152,16 @@ DEVINL unsigned prefetch_next(const ChainOp& nx, const Ctx& c) {
 // Every wave first waits until its own stores have been acknowledged by L2 -- explicitly: __syncthreads() alone is a
 // workgroup-scope fence, which on this target does NOT wait for vmcnt (the waves of a workgroup share one L1) -- then one
 // thread announces the workgroup and polls the XCD's counter, while all threads touch the next op's weights.
-DEVINL bool cluster_barrier(Ctx& c, const ChainOp* next) {
+static DEVINL bool cluster_barrier(Ctx& c, const ChainOp* next) {
   c.gen += (unsigned)c.cs;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
-  if (c.tid == 0) ctr_add(c.bar, 1u);
+  if (c.tid == 0 && !c.skip_arrive) ctr_add(c.bar, 1u);
   const unsigned sink = next ? prefetch_next(*next, c) : 0u;
   if (c.tid == 0) {
     unsigned spins = 0, ok = 1;
     while (ctr_load(c.bar) < c.gen) {
-      if (++spins > SPIN_LIMIT) { (void)__hip_atomic_exchange(&c.sync->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
+      if (++spins > c.spin_limit) { raise_abort(c); ok = 0; break; }
       if ((spins & 1023u) == 0 && ctr_load(&c.sync->abort_flag)) { ok = 0; break; }
     }
     *c.flag = ok;
@@ -163,23 +181,25 @@ DEVINL bool cluster_barrier(Ctx& c, const ChainOp* next) {
 // per-lane-row pattern would ask for the same line once per instruction, and the request rate, not the bandwidth, was the
 // limit) -- and is turned into MFMA fragments through a wave-private LDS tile.  B (weights) goes straight to registers:
 // its lines stay in L1 between the four instructions that walk them.
-struct Frag { float2 araw[8]; float w[16]; };
+static constexpr int NA8 = TROWS / 4;           // 8-byte A loads per lane and chunk (16 lanes per row, 4 rows per instruction)
+static constexpr int NA16 = TROWS / 8;          // 16-byte A loads per lane and chunk (8 lanes per row, 8 rows per instruction)
+struct Frag { float2 araw[NA8]; float w[16]; };
 
-DEVINL void load_frag(Frag& f, const GemmHot& g, const int4 d, int b0, int B, int lane, int brow, int fh) {
+static DEVINL void load_frag(Frag& f, const GemmHot& g, const int4 d, int b0, int B, int lane, int brow, int fh) {
   const bool s2 = (d.w & 1) != 0;
   const int lda = s2 ? g.lda2 : g.lda;
   const float* ap = (s2 ? g.A2 : g.A) + d.x + (lane & 15) * 2;
   const float* wp = (s2 ? g.W2 : g.W) + d.y + (long long)brow * (s2 ? g.Kp2 : g.Kp) + 16 * fh;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) f.araw[i] = ld2(ap + (long long)min(b0 + (lane >> 4) + 4 * i, B - 1) * lda);
+  for (int i = 0; i < NA8; ++i) f.araw[i] = ld2(ap + (long long)min(b0 + (lane >> 4) + 4 * i, B - 1) * lda);
 #pragma unroll
   for (int j = 0; j < 4; ++j) { const float4 v = ldw4(wp + 4 * j); f.w[4 * j] = v.x; f.w[4 * j + 1] = v.y; f.w[4 * j + 2] = v.z; f.w[4 * j + 3] = v.w; }
 }
 
 // araw -> this wave's LDS tile -> a[16] = A[row fi][16 fh + j]
-DEVINL void stage_frag(const Frag& f, float* tile, int lane, float* a) {
+static DEVINL void stage_frag(const Frag& f, float* tile, int lane, float* a) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) *reinterpret_cast<float2*>(tile + ((lane >> 4) + 4 * i) * A_LD + (lane & 15) * 2) = f.araw[i];
+  for (int i = 0; i < NA8; ++i) *reinterpret_cast<float2*>(tile + ((lane >> 4) + 4 * i) * A_LD + (lane & 15) * 2) = f.araw[i];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // same wave: LDS executes in order; keep the compiler from reordering
   const float* rp = tile + (lane & 31) * A_LD + 16 * (lane >> 5);
 #pragma unroll
@@ -191,9 +211,9 @@ DEVINL void stage_frag(const Frag& f, float* tile, int lane, float* a) {
 // lanes per 128-byte row -- 8-byte sc1 loads run at 0.54-0.70x the 16-byte rate), all issued by inline asm so that the wait in
 // front of a chunk is exactly "everything but the next chunk's eight loads" instead of whatever the compiler's scoreboard
 // makes of a loop with conditional refills.  The fragments stay in their slots (never copied) until wait_fragm names them.
-struct FragM { f32x4n a[4]; f32x4n w[4]; };
+struct FragM { f32x4n a[NA16]; f32x4n w[4]; };
 
-DEVINL void load_fragm(FragM& f, const GemmHot& g, const int4 d, int b0, int B, int lane, int brow, int fh) {
+static DEVINL void load_fragm(FragM& f, const GemmHot& g, const int4 d, int b0, int B, int lane, int brow, int fh) {
   const bool s2 = (d.w & 1) != 0;
   const int lda = s2 ? g.lda2 : g.lda;
   const float* ap = (s2 ? g.A2 : g.A) + d.x + (lane & 7) * 4;
@@ -201,19 +221,24 @@ DEVINL void load_fragm(FragM& f, const GemmHot& g, const int4 d, int b0, int B, 
 #pragma unroll
   for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(f.w[j]) : "v"(wp + 4 * j) : "memory");
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < NA16; ++i) {
     const float* p = ap + (long long)min(b0 + (lane >> 3) + 8 * i, B - 1) * lda;
     asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(f.a[i]) : "v"(p) : "memory");
   }
 }
 // younger: the next chunk's eight loads were issued after this chunk's and may stay in flight
-DEVINL void wait_fragm(FragM& f, bool younger) {
-  if (younger) asm volatile("s_waitcnt vmcnt(8)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
-  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+static DEVINL void wait_fragm(FragM& f, bool younger) {
+  if constexpr (NA16 == 4) {
+    if (younger) asm volatile("s_waitcnt vmcnt(8)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+  } else {                                                    // 16-row tiles: six loads per chunk
+    if (younger) asm volatile("s_waitcnt vmcnt(6)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+  }
 }
-DEVINL void stage_fragm(const FragM& f, float* tile, int lane, float* a) {
+static DEVINL void stage_fragm(const FragM& f, float* tile, int lane, float* a) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4n*>(tile + ((lane >> 3) + 8 * i) * A_LD + (lane & 7) * 4) = f.a[i];
+  for (int i = 0; i < NA16; ++i) *reinterpret_cast<f32x4n*>(tile + ((lane >> 3) + 8 * i) * A_LD + (lane & 7) * 4) = f.a[i];
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   const float* rp = tile + (lane & 31) * A_LD + 16 * (lane >> 5);
 #pragma unroll
@@ -223,7 +248,7 @@ DEVINL void stage_fragm(const FragM& f, float* tile, int lane, float* a) {
 
 // Short-K GEMMs (1x1 convolutions, the 1x1 level): one unit per WAVE, the whole K walked by that wave -- no K split, no
 // cross-wave reduction, no workgroup barrier inside the unit loop, and up to 8 x 32 units in flight per cluster instead of 32.
-DEVINL void chain_gemm_wpu(const GemmHot& g, const GemmCold& cold, int P, bool gn, Ctx& c) {
+static DEVINL void chain_gemm_wpu(const GemmHot& g, const GemmCold& cold, int P, bool gn, Ctx& c) {
   const int fi = c.lane & 31, fh = c.lane >> 5;
   const int nblk = (cold.nstore + 31) >> 5;
   const int units = P * nblk;
@@ -249,7 +274,7 @@ DEVINL void chain_gemm_wpu(const GemmHot& g, const GemmCold& cold, int P, bool g
       if (gn) { gs = ldw4(cold.gn_s + (long long)p * g.Npad + n); gb = ldw4(cold.gn_b1 + (long long)p * g.Npad + n); }
       if (cold.R) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const int bb = c.b0 + er + 8 * t; if (bb < c.B) rv[t] = ld4(cold.R + ((long long)hd.w * c.B + bb) * cold.ldr + n); }
+        for (int t = 0; t < NA16; ++t) { const int bb = c.b0 + er + 8 * t; if (bb < c.B) rv[t] = ld4(cold.R + ((long long)hd.w * c.B + bb) * cold.ldr + n); }
       }
     }
     f32x16 acc;
@@ -287,7 +312,7 @@ DEVINL void chain_gemm_wpu(const GemmHot& g, const GemmCold& cold, int P, bool g
     for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * fh) * A_LD + fi] = acc[r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NA16; ++t) {
       const int row = er + 8 * t, bb = c.b0 + row;
       const float4 tv = *reinterpret_cast<const float4*>(tile + row * A_LD + c4);
       float v[4] = {tv.x, tv.y, tv.z, tv.w};
@@ -314,7 +339,7 @@ DEVINL void chain_gemm_wpu(const GemmHot& g, const GemmCold& cold, int P, bool g
   }
 }
 
-DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
+static DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
   TR(0);
   const GemmHot g = uniform_copy(m.g);
   const GemmCold cold = uniform_copy(m.cold);
@@ -362,7 +387,7 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
     const int brow = min(n0 + fi, g.Npad - 1);
     // epilogue operands do not depend on the product: ask for them first
     const int n = n0 + c4, bb = c.b0 + row;
-    const bool ok = c.tid < 256 && n < cold.nstore && bb < c.B;
+    const bool ok = c.tid < 256 && row < TROWS && n < cold.nstore && bb < c.B;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), gs = bv, gb = bv, rv = bv;
     if (ok) {
       if (cold.bias) bv = ldw4(cold.bias + (long long)p * cold.bias_pix_stride + n);
@@ -437,7 +462,7 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
     if (cold.stat_out && c.tid < 256) {
 #pragma unroll
       for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
-      if ((c.tid & 7) == 0 && bb < c.B) cold.stat_out[((long long)p * nblk + nb) * c.B + bb] = make_float2(s, q);
+      if ((c.tid & 7) == 0 && row < TROWS && bb < c.B) cold.stat_out[((long long)p * nblk + nb) * c.B + bb] = make_float2(s, q);
     }
     __syncthreads();                                           // red is reused by the next unit
     TR(4);
@@ -445,15 +470,15 @@ DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
 }
 
 // depthwise 7x7 + bias + time condition + GroupNorm partial per (pixel, sample); see dwconv7_kernel
-DEVINL void chain_dw(const DwArgs& dsrc, Ctx& c) {
+static DEVINL void chain_dw(const DwArgs& dsrc, Ctx& c) {
   const DwArgs d = uniform_copy(dsrc);
-  const int P = d.H * d.W, npairs = P * 32;
+  const int P = d.H * d.W, npairs = P * TROWS;
   const int lanes = d.C / 4 < NT ? d.C / 4 : NT, spb = NT / lanes;   // threads per (pixel, sample) pair, pairs per pass
   const int sl = c.tid / lanes, cl = c.tid - sl * lanes;
   float2* red = reinterpret_cast<float2*>(c.smem);
   for (int base = 0; base < npairs; base += c.cs * spb) {
     const int qi = base + c.slot * spb + sl;
-    const int p = qi >> 5, b = c.b0 + (qi & 31);
+    const int p = qi / TROWS, b = c.b0 + (qi % TROWS);
     const bool active = sl < spb && qi < npairs && b < c.B;
     float s = 0.f, q = 0.f;
     if (active) {
@@ -512,13 +537,13 @@ DEVINL void chain_dw(const DwArgs& dsrc, Ctx& c) {
 // LinearAttention core, one wave per (sample, head); see linattn_kernel
 // n <= 16: every global load of a task (k for all pixels, this half's q, the v tile) is issued before the first use; the
 // arithmetic and its order are those of linattn_kernel.
-DEVINL void chain_linattn16(const AttnArgs a, Ctx& c) {
+static DEVINL void chain_linattn16(const AttnArgs a, Ctx& c) {
   float* my = c.smem + c.wave * 1120;
   float (*ctx)[33] = reinterpret_cast<float (*)[33]>(my);      // overlays the v tile: v is dead once ctx is formed
   float* sv = my;                                              // [pixel][32]
   float (*qs)[32] = reinterpret_cast<float (*)[32]>(my + 32 * 33);
   const int d = c.lane & 31, half = c.lane >> 5;
-  const int ntask = 32 * a.heads, hd = a.heads * 32;
+  const int ntask = TROWS * a.heads, hd = a.heads * 32;
   const long long pstride = (long long)a.B * a.ldq;
   for (int base = 0; base < ntask; base += c.cs * NW) {
     const int t = base + c.slot * NW + c.wave;
@@ -590,14 +615,14 @@ DEVINL void chain_linattn16(const AttnArgs a, Ctx& c) {
   }
 }
 
-DEVINL void chain_linattn(const AttnArgs& asrc, Ctx& c) {
+static DEVINL void chain_linattn(const AttnArgs& asrc, Ctx& c) {
   const AttnArgs a = uniform_copy(asrc);
   if (a.n <= 16) { chain_linattn16(a, c); return; }
   float* my = c.smem + c.wave * 1120;
   float (*ctx)[33] = reinterpret_cast<float (*)[33]>(my);
   float (*qs)[32] = reinterpret_cast<float (*)[32]>(my + 32 * 33);
   const int d = c.lane & 31, half = c.lane >> 5;
-  const int ntask = 32 * a.heads, hd = a.heads * 32;
+  const int ntask = TROWS * a.heads, hd = a.heads * 32;
   const long long pstride = (long long)a.B * a.ldq;
   for (int base = 0; base < ntask; base += c.cs * NW) {
     const int t = base + c.slot * NW + c.wave;
@@ -650,12 +675,12 @@ DEVINL void chain_linattn(const AttnArgs& asrc, Ctx& c) {
 }
 
 // softmax attention core, n <= 16 inside the chain; one wave per (sample, head); see attn_kernel
-DEVINL void chain_attn(const AttnArgs& asrc, Ctx& c) {
+static DEVINL void chain_attn(const AttnArgs& asrc, Ctx& c) {
   const AttnArgs a = uniform_copy(asrc);
   float* my = c.smem + c.wave * 1088;
   float (*sk)[17] = reinterpret_cast<float (*)[17]>(my);
   float (*sv)[17] = reinterpret_cast<float (*)[17]>(my + 32 * 17);
-  const int ntask = 32 * a.heads, hd = a.heads * 32;
+  const int ntask = TROWS * a.heads, hd = a.heads * 32;
   const long long pstride = (long long)a.B * a.ldq;
   for (int base = 0; base < ntask; base += c.cs * NW) {
     const int t = base + c.slot * NW + c.wave;
@@ -693,11 +718,11 @@ DEVINL void chain_attn(const AttnArgs& asrc, Ctx& c) {
 }
 
 // y = GroupNorm(1,C)(u) * gamma + beta + x, one workgroup per sample; see gn_res_kernel
-DEVINL void chain_gn_res(const GnResArgs& gsrc, Ctx& c) {
+static DEVINL void chain_gn_res(const GnResArgs& gsrc, Ctx& c) {
   const GnResArgs g = uniform_copy(gsrc);
   double* rs = reinterpret_cast<double*>(c.smem);              // [NT] sums, [NT] squares
   double* rq = rs + NT;
-  for (int r = c.slot; r < 32; r += c.cs) {
+  for (int r = c.slot; r < TROWS; r += c.cs) {
     const int b = c.b0 + r;
     if (b >= c.B) break;
     double s = 0.0, q = 0.0;
@@ -725,16 +750,22 @@ DEVINL void chain_gn_res(const GnResArgs& gsrc, Ctx& c) {
   }
 }
 
+};  // struct ChainImpl
+
 }  // namespace
 
-__global__ __launch_bounds__(NT) void chain_kernel(const ChainOp* __restrict__ ops, int count, ChainSync* sync, int B, unsigned long long* dbg) {
-  __shared__ __attribute__((aligned(16))) float smem[SMEM_F];
+template <int NT, int GROUPS>
+__global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainOp* __restrict__ ops, int count, ChainSync* sync, int B, unsigned long long* dbg, const ChainCtl ctl) {
+  using K = ChainImpl<NT, GROUPS>;
+  using Ctx = typename K::Ctx;
+  __shared__ __attribute__((aligned(16))) float smem[K::SMEM_F];
   __shared__ __attribute__((aligned(16))) ChainOp sops[CHAIN_MAX_OPS];
   __shared__ float2 mr[32];
   __shared__ unsigned info[8];
   Ctx c;
   c.tid = threadIdx.x; c.lane = c.tid & 63; c.wave = __builtin_amdgcn_readfirstlane(c.tid >> 6);
   c.smem = smem; c.mr = mr; c.flag = &info[7]; c.sync = sync; c.B = B; c.gen = 0; c.tr = nullptr;
+  c.spin_limit = ctl.spin_limit ? ctl.spin_limit : SPIN_LIMIT; c.abort_host = ctl.abort_host;
   {                                                            // stage the op descriptors
     const int nw = count * (int)(sizeof(ChainOp) / 4);
     const int* src = reinterpret_cast<const int*>(ops);
@@ -742,49 +773,68 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainOp* __restrict__ o
     for (int i = c.tid; i < nw; i += NT) dst[i] = src[i];
   }
   const unsigned xcc = xcc_id();
-  // ---- registration: which XCD am I on, who else is here ----
+  // ---- registration: which XCD am I on, who else is here.  A launch that finds the abort flag of an EARLIER launch still
+  //      set (the host has not reset the state yet) does nothing at all: it must not touch counters that may be inconsistent.
   if (c.tid == 0) {
-    const unsigned slot = ctr_add(&sync->count[xcc], 1u);
-    ctr_add(&sync->arrived, 1u + (slot >> 31));                // issued only after `slot` has come back
-    unsigned spins = 0, ok = 1;
-    while (ctr_load(&sync->arrived) < gridDim.x) {
-      if (++spins > SPIN_LIMIT) { (void)__hip_atomic_exchange(&sync->abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = 0; break; }
-      __builtin_amdgcn_s_sleep(1);
+    unsigned ok = ctr_load(&sync->abort_flag) ? 0u : 1u, slot = 0;
+    info[6] = ok;                                              // 0: stale abort, leave without registering
+    if (ok) {
+      slot = ctr_add(&sync->count[xcc], 1u);
+      ctr_add(&sync->arrived, 1u + (slot >> 31));              // issued only after `slot` has come back
+      unsigned spins = 0;
+      while (ctr_load(&sync->arrived) < gridDim.x) {
+        if (++spins > c.spin_limit) { K::raise_abort(c); ok = 0; break; }
+        if ((spins & 255u) == 0 && ctr_load(&sync->abort_flag)) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
-    unsigned nact = 0, ci = 0;
-    for (unsigned i = 0; i < 8; ++i) { const unsigned n = ctr_load(&sync->count[i]); if (n) { if (i < xcc) ++ci; ++nact; } }
-    info[0] = slot; info[1] = ctr_load(&sync->count[xcc]); info[2] = ci; info[3] = nact; info[4] = ok;
+    // clusters: the workgroups of an XCD are dealt round-robin (by arrival) to GROUPS groups; cluster = (XCD, group)
+    const unsigned grp = slot % GROUPS;
+    unsigned nact = 0, ci = 0, mine = 0;
+    for (unsigned i = 0; i < 8; ++i) {
+      const unsigned n = ctr_load(&sync->count[i]);
+      for (unsigned g = 0; g < GROUPS; ++g) {
+        const unsigned sz = (n + GROUPS - 1 - g) / GROUPS;
+        if (i == xcc && g == grp) mine = sz;
+        if (sz) { if (i < xcc || (i == xcc && g < grp)) ++ci; ++nact; }
+      }
+    }
+    info[0] = slot / GROUPS; info[1] = mine; info[2] = ci; info[3] = nact; info[4] = ok; info[5] = grp;
   }
   __syncthreads();
+  if (!info[6]) return;
   c.slot = (int)info[0]; c.cs = (int)info[1];
   const int ci = (int)info[2], nact = (int)info[3];
   bool alive = info[4] != 0;
-  c.bar = &sync->bar[xcc * 16];
-  const int tiles = (B + 31) >> 5;
+  const unsigned cl = xcc * GROUPS + info[5];                  // cluster id
+  c.bar = &sync->bar[cl * 16];
+  c.skip_arrive = ctl.debug_skip && ci == 0 && c.slot == 0;     // test knob: this workgroup never announces itself at a barrier
+  const int tiles = (B + K::TROWS - 1) / K::TROWS;
   const bool stamp = dbg && ci == 0 && c.slot == 0 && c.tid == 0;
   if (stamp) dbg[0] = __builtin_amdgcn_s_memtime();
   for (int tile = ci; alive && tile < tiles; tile += nact) {
-    c.b0 = tile * 32;
+    c.b0 = tile * K::TROWS;
     for (int k = 0; alive && k < count; ++k) {
       c.tr = stamp && tile == ci ? dbg + 1 + 2 * count + 8 * k : nullptr;
       const ChainOp& op = sops[k];
       const int kind = __builtin_amdgcn_readfirstlane(op.kind);
       switch (kind) {
-        case OP_GEMM: chain_gemm(op.gm, __builtin_amdgcn_readfirstlane(op.P), c); break;
-        case OP_DWCONV7: chain_dw(op.d, c); break;
-        case OP_LINATTN: chain_linattn(op.a, c); break;
-        case OP_ATTN: chain_attn(op.a, c); break;
-        case OP_GN_RES: chain_gn_res(op.r, c); break;
+        case OP_GEMM: K::chain_gemm(op.gm, __builtin_amdgcn_readfirstlane(op.P), c); break;
+        case OP_DWCONV7: K::chain_dw(op.d, c); break;
+        case OP_LINATTN: K::chain_linattn(op.a, c); break;
+        case OP_ATTN: K::chain_attn(op.a, c); break;
+        case OP_GN_RES: K::chain_gn_res(op.r, c); break;
         default: break;
       }
       if (stamp && tile == ci) dbg[1 + 2 * k] = __builtin_amdgcn_s_memtime();        // this workgroup finished op k
-      alive = cluster_barrier(c, k + 1 < count ? &sops[k + 1] : nullptr);
+      alive = K::cluster_barrier(c, k + 1 < count ? &sops[k + 1] : nullptr);
       if (stamp && tile == ci) dbg[2 + 2 * k] = __builtin_amdgcn_s_memtime();        // the whole cluster has
     }
   }
-  // ---- leave: the last workgroup of the XCD clears its barrier counter, the last of the grid the registration ----
-  if (c.tid == 0) {
-    if (ctr_add(&sync->left[xcc * 16], 1u) == (unsigned)c.cs - 1u) { ctr_zero(&sync->bar[xcc * 16]); ctr_zero(&sync->left[xcc * 16]); }
+  // ---- leave: the last workgroup of the cluster clears its barrier counter, the last of the grid the registration.
+  //      After an abort nothing is cleared: the host resets the whole block before the next launch (api.hip). ----
+  if (c.tid == 0 && !ctr_load(&sync->abort_flag)) {
+    if (ctr_add(&sync->left[cl * 16], 1u) == (unsigned)c.cs - 1u) { ctr_zero(&sync->bar[cl * 16]); ctr_zero(&sync->left[cl * 16]); }
     if (ctr_add(&sync->done, 1u) == gridDim.x - 1u) {
       for (int i = 0; i < 8; ++i) ctr_zero(&sync->count[i]);
       ctr_zero(&sync->arrived); ctr_zero(&sync->done);
@@ -793,6 +843,20 @@ __global__ __launch_bounds__(NT) void chain_kernel(const ChainOp* __restrict__ o
 }
 
 unsigned long long* g_chain_dbg = nullptr;   // diagnostics only (sbm_debug_chain_stamps)
+
+int chain_variant_groups() { return 1; }   // two interleaved 16-sample clusters per XCD (GROUPS = 2, 256-thread workgroups) measured SLOWER: DESIGN section 8
+
+// The chain kernel's barriers need every workgroup of the grid resident at once.  Checked against the occupancy calculator at
+// model creation (api.hip): grid = workgroups per CU (1 x 512 threads, or 2 x 256) x CUs, never more than fits.
+const char* chain_launch_geometry(int cus, int* grid, int* block) {
+  const int groups = chain_variant_groups();
+  int per_cu = 0;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chain_kernel<512, 1>, 512, 0);
+  if (e != hipSuccess) return "chain kernel: occupancy query failed";
+  if (per_cu < groups) return "chain kernel: the device cannot keep the whole grid resident (occupancy below the cluster design)";
+  *grid = groups * cus; *block = 512;
+  return nullptr;
+}
 
 const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st) {
   if (!dp.chain_ops || !dp.chain_sync) return "chain kernel: no op table";
@@ -807,8 +871,8 @@ const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st
   for (int done = 0; done < count; done += CHAIN_MAX_OPS) {
     const ChainOp* ops = dp.chain_ops + first + done;
     const int n = count - done < CHAIN_MAX_OPS ? count - done : CHAIN_MAX_OPS;
-    if (g_prof_start) hipExtLaunchKernelGGL(chain_kernel, dim3(dp.chain_grid), dim3(NT), 0, st, g_prof_start, g_prof_stop, 0, ops, n, dp.chain_sync, plan.B, g_chain_dbg);
-    else hipLaunchKernelGGL(chain_kernel, dim3(dp.chain_grid), dim3(NT), 0, st, ops, n, dp.chain_sync, plan.B, g_chain_dbg);
+    if (g_prof_start) hipExtLaunchKernelGGL((chain_kernel<512, 1>), dim3(dp.chain_grid), dim3(512), 0, st, g_prof_start, g_prof_stop, 0, ops, n, dp.chain_sync, plan.B, g_chain_dbg, dp.chain_ctl);
+    else hipLaunchKernelGGL((chain_kernel<512, 1>), dim3(dp.chain_grid), dim3(512), 0, st, ops, n, dp.chain_sync, plan.B, g_chain_dbg, dp.chain_ctl);
   }
   return nullptr;
 }

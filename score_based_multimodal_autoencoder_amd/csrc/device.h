@@ -65,14 +65,19 @@ struct ChainOp {
   union { ChainGemm gm; DwArgs d; AttnArgs a; GnResArgs r; };
 };
 constexpr int CHAIN_MAX_OPS = 96;   // ops per launch (their descriptors are staged in LDS)
-struct ChainSync {
+struct ChainSync {          // all zero between launches
   unsigned count[8];        // workgroups registered per XCD
   unsigned arrived;         // total registered
   unsigned done;            // workgroups that finished (the last one resets the registration state)
-  unsigned abort_flag;      // set when a barrier timed out (results are then invalid)
+  unsigned abort_flag;      // set when a barrier timed out (results are then invalid); sticky until the host resets the block
   unsigned pad[5];
-  unsigned bar[8 * 16];     // one barrier counter per XCD, 64 bytes apart
-  unsigned left[8 * 16];    // workgroups of the XCD that have finished (the last one resets bar)
+  unsigned bar[16 * 16];    // one barrier counter per cluster = (XCD, group), 64 bytes apart
+  unsigned left[16 * 16];   // workgroups of the cluster that have finished (the last one resets bar)
+};
+struct ChainCtl {           // launch-invariant controls, passed by value
+  unsigned* abort_host;     // host-mapped word the kernel also raises on a time-out (the API polls it without synchronising)
+  unsigned spin_limit;      // barrier polls before giving up (0 = default, ~0.1 s)
+  unsigned debug_skip;      // test knob: one workgroup never arrives at its barriers, so that they time out
 };
 
 // A plan resolved against its device arenas.
@@ -84,10 +89,13 @@ struct DevPlan {
   const float* aux = nullptr;   // per-call auxiliary input (UNetModel z), copied into ws[plan.aux_off] by run_plan
   const ChainOp* chain_ops = nullptr;   // device array, one entry per plan op (filled for chain ops)
   ChainSync* chain_sync = nullptr;
-  int chain_grid = 256;
+  int chain_grid = 256, chain_block = 512;
+  ChainCtl chain_ctl{};
   const StepCtl* ctl = nullptr;         // sampler control block (score nets)
 };
 const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st);
+const char* chain_launch_geometry(int cus, int* grid, int* block);   // verifies that the whole grid can be resident
+int chain_variant_groups();
 bool qkv_linattn_fusable(const Plan& plan, int i);            // ops i (to_qkv GEMM) and i + 1 (LinearAttention core)
 const char* launch_qkv_linattn(const DevPlan& dp, int i, hipStream_t st);
 const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, float* ws, const GemmCold* cold_dev, GemmHot* hot, GemmCold* cold);
@@ -126,6 +134,8 @@ struct StepArgs {
   const float* alphas;     // (N,) device: 1 - linspace(b0/N, b1/N, N)  (corrector)
   float* x_out; float* mean_out;
   float* norms;            // (B, 2) scratch: per-sample ||score||, ||noise||
+  const double* norm_sums; // exact sharded corrector: (2,) sums of the per-sample norms over the GLOBAL batch (null: reduce the local batch)
+  long long B_global;      // ... and the global batch size the means divide by
   unsigned long long seed; unsigned long long sample_offset;   // Philox key / global sample index of row 0
   int step_base;           // step index used when step_counter is null
   int draw;                // which draw of the step this is (0 = predictor, 1.. = corrector iterations)
@@ -136,6 +146,8 @@ struct StepArgs {
 void launch_em_step(const StepArgs& a, hipStream_t st);
 void launch_ddpm_step(const StepArgs& a, float sqrt_recip_alpha, float beta, float sqrt_one_minus_abar, float sigma, hipStream_t st);
 void launch_langevin_step(const StepArgs& a, hipStream_t st);   // norms + update (two kernels)
+void launch_langevin_norms(const StepArgs& a, double* sums_out, hipStream_t st);   // norms + their fp64 sums (2,)
+void launch_langevin_update(const StepArgs& a, hipStream_t st);  // update alone (a.norm_sums set, or a.norms filled)
 void launch_fill_time(float* t_out, const float* timesteps, const int* step_counter, int B, hipStream_t st);
 void launch_advance(int* step_counter, hipStream_t st);
 void launch_fill_normal(float* out, long long n_per_sample, int B, unsigned long long seed, unsigned long long sample_offset,

@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(const StepArgs a) 
   rs[tid] = s; rn[tid] = n;
   __syncthreads();
   for (int o = 128; o >= 1; o >>= 1) { if (tid < o) { rs[tid] += rs[tid + o]; rn[tid] += rn[tid + o]; } __syncthreads(); }
-  const float gnorm = rs[0] / (float)a.B, nnorm = rn[0] / (float)a.B;
+  float gnorm = rs[0] / (float)a.B, nnorm = rn[0] / (float)a.B;
+  if (a.norm_sums) {       // exact sharded mode: the batch means are over the GLOBAL batch (sums all-reduced by the host side)
+    gnorm = (float)(a.norm_sums[0] / (double)a.B_global); nnorm = (float)(a.norm_sums[1] / (double)a.B_global);
+  }
   const long long idx = (long long)blockIdx.x * blockDim.x + tid;
   const int q4 = a.CHW >> 2;
   if (idx >= (long long)a.B * q4) return;
@@ -233,6 +236,27 @@ void launch_em_step(const StepArgs& a, hipStream_t st) {
 }
 void launch_langevin_step(const StepArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(norms_kernel, dim3(a.B), dim3(256), 0, st, a);
+  const long long n = (long long)a.B * (a.CHW >> 2);
+  hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+}
+// Exact sharded corrector (sde_helper2.py:97-99 takes the MEAN over the whole batch): a shard's part of the two sums in fp64.
+// A double holds the sum of a few thousand floats of similar magnitude exactly, so the total does not depend on how the batch
+// is split nor on the order of the additions: sharded and unsharded runs agree bit for bit.
+__global__ __launch_bounds__(256) void norm_sums_kernel(const float* norms, int B, double* out) {
+  __shared__ double rs[256], rn[256];
+  const int tid = threadIdx.x;
+  double s = 0.0, n = 0.0;
+  for (int i = tid; i < B; i += 256) { s += (double)norms[2 * i]; n += (double)norms[2 * i + 1]; }
+  rs[tid] = s; rn[tid] = n;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) { if (tid < o) { rs[tid] += rs[tid + o]; rn[tid] += rn[tid + o]; } __syncthreads(); }
+  if (tid == 0) { out[0] = rs[0]; out[1] = rn[0]; }
+}
+void launch_langevin_norms(const StepArgs& a, double* sums_out, hipStream_t st) {
+  hipLaunchKernelGGL(norms_kernel, dim3(a.B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(norm_sums_kernel, dim3(1), dim3(256), 0, st, a.norms, a.B, sums_out);
+}
+void launch_langevin_update(const StepArgs& a, hipStream_t st) {
   const long long n = (long long)a.B * (a.CHW >> 2);
   hipLaunchKernelGGL(langevin_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
 }

@@ -520,3 +520,61 @@ def ddpm_cases():
 
 if __name__ == "__main__" and "ddpm" in sys.argv[1:]:
     ddpm_cases()
+
+
+# ---------------------------------------------------------------------------------------------
+# Configs 4 and 5 of BASELINE.json as sampler WORKLOADS (not single forwards): the real sde_helper2.uncond_sampler (order 'cp',
+# the unmodified entry point) and the calc_perf order ('pc': em_predictor then corrector, train_lat_celebhq_unet_cont2.py:305-307)
+# around the full-width score nets -- Unet(256, ch=3, (1,2,2,2,2)) on (B,3,16,16) (train_lat_celebhq_unet_cont2.py:472) and
+# UNetModel(3,128,3,2,(),0.1,(1,2,4,8),use_z,z_dim=512) + z_cond (train_lat_celebhq_unet_cont2_cond.py:651-653) -- N = 10 steps,
+# B = 2, VPSDE(0.1, 5.0) -- NOT train_cel.sh:11's beta_max = 20: the closed-form filler weights do not make a contracting score, and
+# with beta_max = 20 over 10 steps the reference itself overflows to NaN in the corrector runs (|x| ~ 1e3 without) --
+# injected noise (regenerable: synth.noise(seed, k, shape), k = draw index, 0 = prior).
+# Then the CelebA decoders on the resulting latents, exactly as calc_perf slices them (:314-319).
+def config45_cases():
+    from unet_openai import UNetModel
+    out = {}
+    B, N, shape = 2, 10, (2, 3, 16, 16)
+    m4 = synth.fill_module_(Unet(dim=256, channels=3, dim_mults=(1, 2, 2, 2, 2), with_time_emb=True).eval())
+    um = synth.fill_module_(UNetModel(3, 128, 3, 2, (), 0.1, (1, 2, 4, 8), num_heads=1, use_z=True, z_dim=512).eval())
+    zc = synth.noise(0xC5, 0, (B, 512))
+    out["c5_zcond"] = zc
+    zct = torch.from_numpy(zc)
+
+    def m5(x, t):            # the semantics the conditional script intends: score_fn(x, t) = UNetModel(x, t, z=z_cond)
+        return um(x, t, z=zct)
+
+    for cfg, model, base in (("c4", m4, 0xC40), ("c5", m5, 0xC50)):
+        for order in ("cp", "pc"):
+            for pc in (False, True):
+                sde = S.VPSDE(0.1, 5.0, N)
+                seed = base + 2 * (order == "pc") + int(pc)
+                with _Noise(seed) as nz:
+                    if order == "cp":
+                        xm = S.uncond_sampler(shape, model, "cpu", sde, pc=pc, n_steps=1, target_snr=0.16)
+                    else:
+                        x = sde.prior_sampling(shape)
+                        ts = torch.linspace(sde.T, 1e-3, sde.N)
+                        for i in range(sde.N):
+                            vt = torch.ones(B) * ts[i]
+                            x, xm = S.em_predictor(x, vt, model, sde)
+                            if pc:
+                                x, xm = S.corrector(x, vt, model, sde, 1, 0.16)
+                tag = f"{cfg}_{order}_pc{int(pc)}"
+                assert len(nz.log) == 1 + N * (1 + int(pc)) and nz.log[0][0] == "randn", [k for k, _ in nz.log]
+                out[tag + "_xmean"] = xm.numpy()
+                out[tag + "_seed"] = np.asarray([seed, len(nz.log)])
+                print(tag, "draws", len(nz.log), "|x_mean| max", float(xm.abs().max()), flush=True)
+    # decoders on the config-4 'pc' (calc_perf order), pc=1 latents: z[mod] = z_mean[:, ind].view(B, size_z)  (:314-319)
+    z = torch.from_numpy(out["c4_pc_pc1_xmean"])
+    img = synth.fill_module_(ResVAEN(CEL_IMG_ENC, CEL_IMG_DEC, 128, 256, 3).eval())
+    msk = synth.fill_module_(ResVAEN(CEL_MASK_ENC, CEL_MASK_DEC, 128, 256, 1).eval())
+    att = synth.fill_module_(CelebAAttrNewBN(256).eval())
+    out["c4_dec_img0"] = img.decoder(z[:, 0].reshape(B, 256)).numpy()[:1]        # sample 0 only (size)
+    out["c4_dec_mask"] = msk.decoder(z[:, 1].reshape(B, 256)).numpy()
+    out["c4_dec_attr"] = att.decoder(z[:, 2].reshape(B, 256)).numpy()
+    save("config45.npz", **out)
+
+
+if __name__ == "__main__" and "cfg45" in sys.argv[1:]:
+    config45_cases()
