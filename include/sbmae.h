@@ -35,7 +35,10 @@ enum sbm_kind {
   SBM_RESENC = 5   /* h_vae_model_copy.ResVAE/ResAE/ResVAEN/ResAEN.encoder: image (B,img_ch,s,s) -> (B, 2*size_z) = [mu | logvar]
                       h_vae_model_copy.py:41-71,379-409; cfg as SBM_RESDEC */,
   SBM_ATTRENC = 6  /* h_vae_model.CelebAAttrNewBN[AE].encoder: attributes (B, att_size) -> (B, 2*size_z) = [mu | logvar] (AE: (B, size_z))
-                      h_vae_model.py:718-736,756-759, 845-863,884-887; cfg [size_z, att_size, ae] */
+                      h_vae_model.py:718-736,756-759, 845-863,884-887; cfg [size_z, att_size, ae] */,
+  SBM_CLG = 7      /* lat_sm2_model.ClwithTime2 / ClwithTime3: the time-conditioned pairwise classifier / energy MLP used for guidance
+                      (train_lat_celebhq_unet_cont2.py:487, train_poly_unet_cont.py:587; the reference imports these names but its
+                      lat_sm2_model.py no longer defines them -- the architecture is this package's); cfg [variant 2|3, n_mod = 2, size_z, n_class] */
 };
 
 /* Integer configuration vectors (`cfg`):
@@ -111,10 +114,11 @@ typedef struct sbm_sde_cfg {
 
 /* One Euler-Maruyama predictor update given the score  == em_predictor minus its score_fn call
  * (sde_helper2.py:45-52; PolyMNIST copy train_poly_unet_cont.py:96-102).
- * noise == NULL: draw N(0,1) in-kernel from Philox keyed by (seed, sample_offset + row, step, draw 0). */
+ * noise == NULL: draw N(0,1) in-kernel from Philox keyed by (seed, sample_offset + row, step, draw); `draw` numbers the draws of one
+ * step in execution order (sbm_sampler_run: corrector iterations first for order 0, the predictor first for order 1). */
 int sbm_em_step(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t,
                 float* x_out, float* mean_out, int B, int CHW, uint64_t seed, uint64_t sample_offset, int step,
-                void* stream);
+                int draw, void* stream);
 
 /* One Langevin corrector iteration given the score  == the loop body of corrector (sde_helper2.py:96-101).
  * alphas: device (N,) = 1 - linspace(b0/N, b1/N, N) (ignored for VE); norms_scratch: device 2*B floats. */
@@ -132,6 +136,17 @@ int sbm_langevin_norms(const float* score, const float* noise, float* norms_scra
 int sbm_langevin_update(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t, const float* alphas,
                         float* x_out, float* mean_out, const double* norm_sums, long B_global, int B, int CHW, uint64_t seed,
                         uint64_t sample_offset, int step, int draw, void* stream);
+
+/* Classifier / energy guidance: for the pair of modalities (ch1, ch2) of the joint state x (B, C, per_mod),
+ *   grad = d mean(cl_g(cat[x[:, ch1], x[:, ch2]].view(B, -1), t [, id1, id2])) / d (the pair)      (B, 2, per_mod)
+ *   score[:, ch1] -= cl_s * grad[:, 0]  (upd_mask bit 0),   score[:, ch2] -= cl_s * grad[:, 1]  (bit 1)      in place
+ * == the `if cl_g is not None and given` branches of RSDE.sde (sde_helper2.py:283-312) and corrector (:65-94); the PolyMNIST variant
+ * (train_poly_unet_cont.py:73-89, 129-146) updates only the predicted modality (upd_mask = 2).  `mean` is over B * n_class outputs,
+ * so the gradient carries the reference's 1 / (B * n_class).  grad_out (B, 2 * per_mod) optional; score_inout may be NULL then.
+ * sbm_clg_forward: cl_g(x_pair, t [, id1, id2]) -> out (B, n_class). */
+int sbm_clg_forward(sbm_model* m, const float* x_pair, const float* t, int id1, int id2, float* out, int B, void* stream);
+int sbm_clg_guide(sbm_model* m, const float* x, const float* t, int ch1, int ch2, int id1, int id2, float cl_s, unsigned upd_mask,
+                  float* score_inout, float* grad_out, int B, int C, int per_mod, void* stream);
 
 /* Fixed-step Langevin update of the alternative samplers, on the joint state (B, n_mod, per_mod):
  *   x_out[:, m] = x[:, m] + a * (score[:, m] / score_div) + b * noise[:, m]  for modalities m with bit m of mod_mask set, x[:, m] otherwise.

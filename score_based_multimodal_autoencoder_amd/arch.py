@@ -307,6 +307,18 @@ def mlp_state_shapes(n_mod=5, size_z=128):
     return dict(mlp_entries(n_mod, size_z))
 
 
+def clg_entries(variant, n_mod=2, size_z=64, n_class=1):
+    """state_dict of lat_sm2_model.ClwithTime2 (variant 2) / ClwithTime3 (variant 3), this package's definition of the guidance
+    MLP the reference imports but no longer ships; mirrors csrc/guidance.hip clg_tensor_specs."""
+    d0 = n_mod * size_z + 128 + (64 if variant == 3 else 0)
+    out = [("time_mlp.0.weight", (128, 64)), ("time_mlp.0.bias", (128,))]
+    if variant == 3:
+        out.append(("mod_emb.weight", (10, 32)))
+    out += [("layers.0.weight", (512, d0)), ("layers.0.bias", (512,)), ("layers.2.weight", (256, 512)), ("layers.2.bias", (256,)),
+            ("layers.4.weight", (n_class, 256)), ("layers.4.bias", (n_class,))]
+    return out
+
+
 def _proj_head(d):
     yield "proj.projection.weight", (d, d)
     yield "proj.projection.bias", (d,)

@@ -43,6 +43,8 @@ struct sbm_model {
   int* d_counter = nullptr;       // StepCtl block (step counter first)
   float* d_time_table = nullptr;  // [table_rows][cond_ld] time-path outputs for every step of the current sampler run
   size_t time_table_floats = 0;
+  long long clg_off[13] = {0};    // SBM_CLG: offsets of the packed guidance-MLP tensors inside d_params (guidance.hip clg_pack)
+  int clg_cfg[4] = {0, 0, 0, 0};  // variant, n_mod, size_z, n_class
   hipStream_t own = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
 };
@@ -74,6 +76,7 @@ static std::vector<TensorSpec> specs_of(int kind, const int* cfg) {
   if (kind == SBM_RESENC) return resenc_tensor_specs(resdec_cfg_from_ints(cfg));
   if (kind == SBM_ATTRENC) { AttrEncCfg c; c.size_z = cfg[0]; c.att_size = cfg[1]; c.ae = cfg[2]; return attrenc_tensor_specs(c); }
   if (kind == SBM_UNET) return unet_tensor_specs(unet_cfg_from_ints(cfg));
+  if (kind == SBM_CLG) return clg_tensor_specs(cfg[0], cfg[1], cfg[2], cfg[3]);
   if (kind == SBM_RESDEC) return resdec_tensor_specs(resdec_cfg_from_ints(cfg));
   if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; return attrdec_tensor_specs(a); }
   return {};
@@ -103,7 +106,7 @@ static int chain_prior_abort(sbm_model* m, hipStream_t st, const char* who) {
 extern "C" {
 
 const char* sbm_last_error(void) { return g_err.c_str(); }
-int sbm_abi_version(void) { return 1; }
+int sbm_abi_version(void) { return 2; }
 
 int sbm_spec_count(int kind, const int* cfg) { return (int)specs_of(kind, cfg).size(); }
 
@@ -145,6 +148,17 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   sbm_model* m = new (std::nothrow) sbm_model();
   if (!m) return fail("out of host memory");
   m->kind = kind;
+  if (kind == SBM_CLG) {                    // guidance MLP: no plan, just the packed matrices
+    std::vector<float> packed; std::string err;
+    if (!clg_pack(cfg[0], cfg[1], cfg[2], cfg[3], host_tensors, &packed, m->clg_off, &err)) { delete m; return fail("sbm_model_create: " + err); }
+    for (int i = 0; i < 4; ++i) m->clg_cfg[i] = cfg[i];
+    hipError_t ce;
+    if ((ce = hipMalloc(&m->d_params, packed.size() * sizeof(float))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(params)", ce); }
+    if ((ce = hipMemcpy(m->d_params, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(params)", ce); }
+    m->plan.B = batch;
+    *out = m;
+    return 0;
+  }
   bool ok = false;
   if (kind == SBM_UNET) ok = build_unet_plan(unet_cfg_from_ints(cfg), batch, host_tensors, &m->plan);
   else if (kind == SBM_RESDEC) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), batch, in_pitch, host_tensors, &m->plan);
@@ -493,10 +507,10 @@ static StepArgs step_args(const sbm_sde_cfg* sde, const float* x, const float* s
 }
 
 int sbm_em_step(const sbm_sde_cfg* sde, const float* x, const float* score, const float* noise, const float* t, float* x_out, float* mean_out,
-                int B, int CHW, uint64_t seed, uint64_t sample_offset, int step, void* stream) {
+                int B, int CHW, uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream) {
   if (!sde || !x || !score || !t || !x_out || !mean_out || B <= 0 || CHW <= 0) return fail("sbm_em_step: bad arguments");
   if (CHW % 4) return fail("sbm_em_step: C*H*W must be a multiple of 4");
-  StepArgs a = step_args(sde, x, score, noise, t, x_out, mean_out, B, CHW, seed, sample_offset, step, 0);
+  StepArgs a = step_args(sde, x, score, noise, t, x_out, mean_out, B, CHW, seed, sample_offset, step, draw);
   launch_em_step(a, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
@@ -512,6 +526,37 @@ int sbm_langevin_step(const sbm_sde_cfg* sde, const float* x, const float* score
   launch_langevin_step(a, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+// ---- classifier / energy guidance ----
+static int clg_run(sbm_model* m, ClgArgs a, void* stream, const char* who) {
+  if (!m || m->kind != SBM_CLG) return fail(std::string(who) + ": not a guidance model handle");
+  if (!a.t || a.B <= 0) return fail(std::string(who) + ": bad arguments");
+  const float* p = m->d_params; const long long* o = m->clg_off;
+  a.Wt_T = p + o[0]; a.bt = p + o[1]; a.emb = o[2] >= 0 ? p + o[2] : nullptr; a.W1 = p + o[3]; a.W1_T = p + o[4]; a.b1 = p + o[5];
+  a.W2 = p + o[6]; a.W2_T = p + o[7]; a.b2 = p + o[8]; a.W3 = p + o[9]; a.b3 = p + o[10]; a.freq = p + o[11];
+  a.D0 = (int)o[12]; a.size_z = m->clg_cfg[2]; a.n_class = m->clg_cfg[3]; a.n_emb = m->clg_cfg[0] == 3 ? 1 : 0;
+  if (a.n_emb && (a.id1 < 0 || a.id1 >= 10 || a.id2 < 0 || a.id2 >= 10)) return fail(std::string(who) + ": modality ids must be in [0, 10)");
+  const char* e = launch_clg(a, (hipStream_t)stream);
+  if (e) return fail(std::string(who) + ": " + e);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int sbm_clg_forward(sbm_model* m, const float* x_pair, const float* t, int id1, int id2, float* out, int B, void* stream) {
+  if (!x_pair || !out) return fail("sbm_clg_forward: bad arguments");
+  ClgArgs a{}; a.x_pair = x_pair; a.t = t; a.id1 = id1; a.id2 = id2; a.out = out; a.B = B;
+  return clg_run(m, a, stream, "sbm_clg_forward");
+}
+
+int sbm_clg_guide(sbm_model* m, const float* x, const float* t, int ch1, int ch2, int id1, int id2, float cl_s, unsigned upd_mask,
+                  float* score_inout, float* grad_out, int B, int C, int per_mod, void* stream) {
+  if (!m || !x || (!score_inout && !grad_out)) return fail("sbm_clg_guide: bad arguments");
+  if (m->kind == SBM_CLG && per_mod != m->clg_cfg[2]) return fail("sbm_clg_guide: a modality's latent size must equal the MLP's size_z");
+  if (ch1 < 0 || ch1 >= C || ch2 < 0 || ch2 >= C) return fail("sbm_clg_guide: modality channel out of range");
+  ClgArgs a{}; a.x = x; a.C = C; a.per_mod = per_mod; a.ch1 = ch1; a.ch2 = ch2; a.t = t; a.id1 = id1; a.id2 = id2;
+  a.score = score_inout; a.cl_s = cl_s; a.upd_mask = upd_mask; a.grad_out = grad_out; a.B = B;
+  return clg_run(m, a, stream, "sbm_clg_guide");
 }
 
 int sbm_langevin_norms(const float* score, const float* noise, float* norms_scratch, double* sums_out, int B, int CHW, uint64_t seed,

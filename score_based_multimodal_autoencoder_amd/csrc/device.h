@@ -143,6 +143,22 @@ struct StepArgs {
   SdeParams sde;
 };
 
+// classifier / energy guidance MLP (guidance.hip): forward + input-VJP of cl_out.mean() + in-place score update
+struct ClgArgs {
+  const float* x; int C, per_mod, ch1, ch2;      // joint state (B, C, per_mod): the pair is x[:, ch1], x[:, ch2] ...
+  const float* x_pair;                           // ... or an explicit (B, 2 * size_z) matrix (forward(x, t) of the module)
+  const float* t; int id1, id2;
+  float* score; float cl_s; unsigned upd_mask;   // score (B, C, per_mod) updated in place: bit 0 -> ch1, bit 1 -> ch2
+  float* grad_out;                               // (B, 2 * size_z) or null
+  float* out;                                    // (B, n_class) or null
+  const float* Wt_T; const float* bt; const float* emb; const float* W1; const float* W1_T; const float* b1;
+  const float* W2; const float* W2_T; const float* b2; const float* W3; const float* b3; const float* freq;
+  int B, size_z, n_class, D0, n_emb;
+};
+const char* launch_clg(const ClgArgs& a, hipStream_t st);
+std::vector<TensorSpec> clg_tensor_specs(int variant, int n_mod, int size_z, int n_class);
+bool clg_pack(int variant, int n_mod, int size_z, int n_class, const float* const* t, std::vector<float>* out, long long* off, std::string* err);
+
 void launch_em_step(const StepArgs& a, hipStream_t st);
 void launch_ddpm_step(const StepArgs& a, float sqrt_recip_alpha, float beta, float sqrt_one_minus_abar, float sigma, hipStream_t st);
 void launch_langevin_step(const StepArgs& a, hipStream_t st);   // norms + update (two kernels)

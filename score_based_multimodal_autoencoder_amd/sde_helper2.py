@@ -6,8 +6,9 @@
 
 The z-updates (Euler-Maruyama predictor, Langevin corrector, their batch-mean norms) and -- when the
 score model is this package's `Unet` -- the whole N-step loop run in the HIP library; the loop is
-captured once into a hipGraph and replayed.  Training-only helpers (loss_fn, JAX importance
-sampling) and classifier guidance are out of scope: passing `cl_g` raises.
+captured once into a hipGraph and replayed.  Classifier / energy guidance (`cl_g`, `cl_s`, `given`, `all_mods`;
+SURVEY.md 8(f4)) is applied by `apply_guidance_` (HIP input-VJP kernel for this package's ClwithTime2/3).
+Training-only helpers (loss_fn, JAX importance sampling) are out of scope.
 
 Additions, all keyword-only and defaulted so reference call sites keep working:
     order  'cp' (corrector then predictor, sde_helper2.uncond_sampler) or
@@ -72,10 +73,10 @@ class _Reverse:
         return self.fwd.T
 
     def sde(self, x, t, cl_g=None, cl_s=None, target=None, given=None, all_mods=None):
-        if cl_g is not None and given:
-            raise NotImplementedError("classifier guidance is out of scope (SURVEY.md 8(f4))")
         drift, diffusion = self.fwd.sde(x, t)
         score = self.score_fn(x, t)
+        if _guided(cl_g, given):
+            score = apply_guidance_(as_f32_cuda(x, "x"), as_f32_cuda(t, "t"), as_f32_cuda(score, "score"), cl_g, cl_s, given, all_mods)
         drift = drift - diffusion[:, None, None, None] ** 2 * score * (0.5 if self.probability_flow else 1.)
         return drift, (torch.zeros_like(diffusion) if self.probability_flow else diffusion)
 
@@ -165,9 +166,47 @@ class VESDE(SDE):
 
 
 # --------------------------------------------------------------------------------------------------
-def _no_guidance(cl_g, given=None):
-    if cl_g is not None and (given is None or given):
-        raise NotImplementedError("classifier / energy guidance (cl_g) is out of scope for this build (SURVEY.md 8(f4))")
+def apply_guidance_(x, t, score, cl_g, cl_s, given, all_mods, poly_pairs=False):
+    """Classifier / energy guidance, in place on `score` (which the reference mutates too): sde_helper2.py:283-312 (RSDE.sde) and
+    :65-94 (corrector) -- for every (given, predicted) pair among '01', '02', '12':
+        new_x = cat[x[:, m1], x[:, m2]];  g = autograd.grad(cl_g[m1 m2](new_x.view(B, -1), t).mean(), new_x)
+        score[:, m1] -= cl_s * g[:, 0];   score[:, m2] -= cl_s * g[:, 1]
+    `poly_pairs`: the PolyMNIST script's variant (train_poly_unet_cont.py:73-89): ONE random (given, predicted) pair per call
+    (two torch.randint draws), cl_g(new_x, t, id1, id2), and only the predicted modality's score is updated.
+    Networks of this package (lat_sm2_model.ClwithTime2/3) take the HIP input-VJP kernel; any other callable goes through
+    torch.autograd on the GPU exactly as in the reference."""
+    if cl_g is None or given is None or not given:
+        return score
+    from .lat_sm2_model import _ClwithTime
+    base = int(all_mods[0])
+    predicted = "".join(m for m in all_mods if m not in given)
+    jobs = []
+    if poly_pairs:
+        mod1 = given[torch.randint(len(given), (1,)).item()]
+        mod2 = predicted[torch.randint(len(predicted), (1,)).item()]
+        jobs.append((cl_g, int(mod1) - base, int(mod2) - base, (False, True), True))
+    else:
+        for m1, m2 in (("0", "1"), ("0", "2"), ("1", "2")):
+            if (m1 in given and m2 in predicted) or (m2 in given and m1 in predicted):
+                jobs.append((cl_g[m1 + m2], int(m1) - base, int(m2) - base, (True, True), False))
+    for net, c1, c2, upd, with_ids in jobs:
+        if isinstance(net, _ClwithTime):
+            net.guide_(x, t, score, c1, c2, cl_s, update=upd, ids=(c1, c2))
+            continue
+        with torch.enable_grad():                                   # a user's own torch module: the reference's autograd path
+            new_x = torch.cat([x[:, c1].unsqueeze(1), x[:, c2].unsqueeze(1)], dim=1).detach().requires_grad_(True)
+            flat = new_x.view(new_x.shape[0], -1)
+            out = net(flat, t, c1, c2) if with_ids else net(flat, t)
+            g = torch.autograd.grad(out.mean(), new_x)[0]
+        if upd[0]:
+            score[:, c1] -= cl_s * g[:, 0]
+        if upd[1]:
+            score[:, c2] -= cl_s * g[:, 1]
+    return score
+
+
+def _guided(cl_g, given):
+    return cl_g is not None and given is not None and bool(given)
 
 
 def _alphas_dev(sde, device):
@@ -190,45 +229,77 @@ def _with_z(score_fn, z_cond):
 
 
 def em_predictor(x, t, score_fn, sde, probability_flow=False, cl_g=None, cl_s=None, target=None, given=None,
-                 all_mods=None, z_cond=None, *, noise=None, score=None):
+                 all_mods=None, z_cond=None, *, noise=None, score=None, philox=None, poly_pairs=False):
     """One reverse-SDE Euler-Maruyama step -> (x, x_mean)   [reference sde_helper2.py:45-52].
 
     `noise`: the randn_like draw (default: torch.randn_like(x), drawn BEFORE the score call like the reference).
-    `score`: a precomputed score_fn(x, t) (skips the call)."""
-    _no_guidance(cl_g, given)
+    `score`: a precomputed score_fn(x, t) (skips the call).
+    `philox`: (seed, sample_offset, step, draw) -- in-kernel counter-based noise keyed by the global sample index.
+    `cl_g`, `cl_s`, `given`, `all_mods`: classifier guidance of the conditional callers (apply_guidance_)."""
     x = as_f32_cuda(x, "x")
     t = as_f32_cuda(t, "t")
-    z = torch.randn_like(x) if noise is None else as_f32_cuda(noise, "noise")
+    seed, off, step, draw = 0, 0, 0, 0
+    if philox is not None:
+        seed, off, step, draw = philox
+        zp = None
+    else:
+        z = torch.randn_like(x) if noise is None else as_f32_cuda(noise, "noise")
+        zp = z.data_ptr()
     s = as_f32_cuda(_with_z(score_fn, z_cond)(x, t) if score is None else score, "score")
+    if _guided(cl_g, given):
+        s = apply_guidance_(x, t, s if score is None else s.clone(), cl_g, cl_s, given, all_mods, poly_pairs)
     B = x.shape[0]
     x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
     cfg = sde._cfg(probability_flow=probability_flow)
-    _lib.check(_lib.lib().sbm_em_step(ctypes.byref(cfg), x.data_ptr(), s.data_ptr(), z.data_ptr(), t.data_ptr(),
-                                      x_new.data_ptr(), x_mean.data_ptr(), B, x[0].numel(), 0, 0, 0, _lib.stream_ptr()))
+    _lib.check(_lib.lib().sbm_em_step(ctypes.byref(cfg), x.data_ptr(), s.data_ptr(), zp, t.data_ptr(),
+                                      x_new.data_ptr(), x_mean.data_ptr(), B, x[0].numel(), seed, off, step, draw,
+                                      _lib.stream_ptr()))
     return x_new, x_mean
 
 
 def corrector(x, t, score_fn, sde, n_steps, target_snr, cl_g=None, cl_s=None, target=None, given=None, all_mods=None,
-              z_cond=None, *, noise=None):
+              z_cond=None, *, noise=None, philox=None, exact_norms=False, norm_reduce=None, global_batch=None, poly_pairs=False):
     """n_steps Langevin corrector iterations -> (x, x_mean)   [reference sde_helper2.py:54-106].
 
-    `noise`: optional list of n_steps injected draws (default torch.randn_like after each score call)."""
-    _no_guidance(cl_g, given)
+    `noise`: optional list of n_steps injected draws (default torch.randn_like after each score call).
+    `philox`: (seed, sample_offset, step, first_draw) -- draw the noise in-kernel from the counter-based stream keyed by the GLOBAL
+      sample index instead (what the fused loop does; independent of how the batch is sharded).
+    `exact_norms`: the step size uses the mean of the per-sample norms over the whole batch (sde_helper2.py:97-99); for a batch
+      sharded over ranks this computes the shard's two sums in fp64, hands them to `norm_reduce(sums)` (default: all-reduce over
+      the default process group; identity for one process) and divides by `global_batch` -- the single-device result, bit for bit."""
     x = as_f32_cuda(x, "x")
     t = as_f32_cuda(t, "t")
     B = x.shape[0]
     cfg = sde._cfg(target_snr=target_snr)
     alphas = _alphas_dev(sde, x.device)
+    ap = alphas.data_ptr() if alphas is not None else None
     norms = torch.empty(2 * B, device=x.device, dtype=torch.float32)
+    seed, off, step, d0 = philox if philox is not None else (0, 0, 0, 0)
+    L = _lib.lib()
     x_mean = x
     for i in range(n_steps):
         g = as_f32_cuda(_with_z(score_fn, z_cond)(x, t), "score")
-        z = torch.randn_like(x) if noise is None else as_f32_cuda(noise[i], "noise")
+        if _guided(cl_g, given):
+            g = apply_guidance_(x, t, g, cl_g, cl_s, given, all_mods, poly_pairs)
+        if philox is not None:
+            zp = None
+        else:
+            z = torch.randn_like(x) if noise is None else as_f32_cuda(noise[i], "noise")
+            zp = z.data_ptr()
         x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
-        _lib.check(_lib.lib().sbm_langevin_step(ctypes.byref(cfg), x.data_ptr(), g.data_ptr(), z.data_ptr(), t.data_ptr(),
-                                                alphas.data_ptr() if alphas is not None else None, x_new.data_ptr(),
-                                                x_mean.data_ptr(), norms.data_ptr(), B, x[0].numel(), 0, 0, 0, i,
-                                                _lib.stream_ptr()))
+        if exact_norms:
+            from . import distributed as D
+            sums = torch.empty(2, device=x.device, dtype=torch.float64)
+            _lib.check(L.sbm_langevin_norms(g.data_ptr(), zp, norms.data_ptr(), sums.data_ptr(), B, x[0].numel(), seed, off, step, d0 + i,
+                                            _lib.stream_ptr()))
+            sums = (norm_reduce or D.langevin_norm_allreduce)(sums)
+            _lib.check(L.sbm_langevin_update(ctypes.byref(cfg), x.data_ptr(), g.data_ptr(), zp, t.data_ptr(), ap, x_new.data_ptr(),
+                                             x_mean.data_ptr(), sums.data_ptr(), int(global_batch or B), B, x[0].numel(), seed, off, step,
+                                             d0 + i, _lib.stream_ptr()))
+        else:
+            _lib.check(L.sbm_langevin_step(ctypes.byref(cfg), x.data_ptr(), g.data_ptr(), zp, t.data_ptr(), ap, x_new.data_ptr(),
+                                           x_mean.data_ptr(), norms.data_ptr(), B, x[0].numel(), seed, off, step, d0 + i,
+                                           _lib.stream_ptr()))
         x = x_new
     return x, x_mean
 
@@ -243,9 +314,16 @@ def _fused_ok(model, z_cond=None):
 
 def uncond_sampler(sample_shape, model, device, sde, eps=1e-3, probability_flow=False, pc=False, n_steps=1,
                    target_snr=0.16, cl_g=None, cl_s=None, target=None, *, order="cp", noise=None, x0=None, seed=None,
-                   sample_offset=0, use_graph=True, return_timing=False, z_cond=None):
-    """N-step predictor(-corrector) sampling; returns the last sub-step's x_mean   [reference sde_helper2.py:115-128]."""
-    _no_guidance(cl_g)
+                   sample_offset=0, use_graph=True, return_timing=False, z_cond=None, exact_sharded_norms=False,
+                   global_batch=None, norm_reduce=None):
+    """N-step predictor(-corrector) sampling; returns the last sub-step's x_mean   [reference sde_helper2.py:115-128].
+
+    `exact_sharded_norms` (with pc=True, batch sharded over ranks): the corrector's step size uses the mean norms of the GLOBAL
+    batch (`global_batch` rows; two fp64 sums all-reduced per corrector iteration by `norm_reduce`, default the default process
+    group) -- the single-device reference result whatever the world size.  Runs the loop from Python (a collective sits inside
+    each step) with the same Philox stream as the fused loop.  Default (False): per-shard means, no in-loop collective.
+    `cl_g` / `cl_s` / `target` are accepted and inert, as in the reference: its uncond_sampler never passes `given`, so the guidance
+    branch (`cl_g is not None and given`) cannot fire (sde_helper2.py:124-126, 283)."""
     if order not in ("cp", "pc"):
         raise ValueError("order must be 'cp' (sde_helper2) or 'pc' (train_poly_unet_cont)")
     device = torch.device(device)
@@ -262,6 +340,21 @@ def uncond_sampler(sample_shape, model, device, sde, eps=1e-3, probability_flow=
             noise = as_f32_cuda(noise, "noise")
             if noise.shape[0] < sde.N * dps:
                 raise ValueError(f"noise needs {sde.N * dps} draws")
+        if exact_sharded_norms and pc:
+            if noise is not None:
+                raise ValueError("exact_sharded_norms draws its noise from the Philox stream (keyed by the global sample index)")
+            seed = fresh_seed(seed)
+            x_mean = x
+            for i in range(sde.N):
+                vec_t = torch.ones(B, device=device) * timesteps[i]
+                kw = dict(z_cond=z_cond, exact_norms=True, norm_reduce=norm_reduce, global_batch=global_batch or B)
+                if order == "cp":
+                    x, x_mean = corrector(x, vec_t, model, sde, n_steps, target_snr, philox=(seed, sample_offset, i, 0), **kw)
+                    x, x_mean = em_predictor(x, vec_t, model, sde, probability_flow, z_cond=z_cond, philox=(seed, sample_offset, i, n_steps))
+                else:
+                    x, x_mean = em_predictor(x, vec_t, model, sde, probability_flow, z_cond=z_cond, philox=(seed, sample_offset, i, 0))
+                    x, x_mean = corrector(x, vec_t, model, sde, n_steps, target_snr, philox=(seed, sample_offset, i, 1), **kw)
+            return x_mean
         if _fused_ok(model, z_cond):
             from .unet_openai import UNetModel
             if isinstance(model, UNetModel):

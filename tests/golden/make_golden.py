@@ -578,3 +578,213 @@ def config45_cases():
 
 if __name__ == "__main__" and "cfg45" in sys.argv[1:]:
     config45_cases()
+
+
+# ---------------------------------------------------------------------------------------------
+# Classifier / energy guidance.  The reference imports ClwithTime2 / ClwithTime3 from lat_sm2_model but no longer
+# defines them (an ImportError of its own): the architecture below is THIS BUILD'S definition (score_based_multimodal_autoencoder_amd/
+# lat_sm2_model.py), written here with plain torch modules so that the reference's own guidance code -- RSDE.sde and corrector of
+# sde_helper2.py (:283-312, :65-94), em_predictor / corrector of train_poly_unet_cont.py (:73-89, :129-146) -- differentiates it with
+# torch.autograd.  The fixtures are the outputs of those unmodified reference functions.
+def _clwithtime_classes():
+    from unet_model import SinusoidalPositionEmbeddings  # (reference)
+    nn = torch.nn
+
+    class _Base(nn.Module):
+        def __init__(self, n_mod=2, size_z=64, n_class=1, ids=False):
+            super().__init__()
+            self.time_mlp = nn.Sequential(nn.Linear(64, 128), nn.Softplus())
+            self.sin = SinusoidalPositionEmbeddings(64)
+            if ids:
+                self.mod_emb = nn.Embedding(10, 32)
+            d0 = n_mod * size_z + 128 + (64 if ids else 0)
+            self.layers = nn.Sequential(nn.Linear(d0, 512), nn.Softplus(), nn.Linear(512, 256), nn.Softplus(), nn.Linear(256, n_class))
+
+        def _run(self, x, t, extra):
+            temb = self.time_mlp(self.sin(t))
+            return self.layers(torch.cat([x, temb] + extra, dim=1))
+
+    class ClwithTime2(_Base):
+        def __init__(self, n_mod=2, size_z=64, n_class=1):
+            super().__init__(n_mod, size_z, n_class, ids=False)
+
+        def forward(self, x, t):
+            return self._run(x, t, [])
+
+    class ClwithTime3(_Base):
+        def __init__(self, n_mod=2, size_z=64, n_class=1):
+            super().__init__(n_mod, size_z, n_class, ids=True)
+
+        def forward(self, x, t, id1, id2):
+            B = x.shape[0]
+            e = [self.mod_emb(torch.full((B,), int(i), dtype=torch.long)) for i in (id1, id2)]
+            return self._run(x, t, e)
+
+    return ClwithTime2, ClwithTime3
+
+
+def _fill_clg(m, salt):
+    """closed-form weights under the state_dict keys of THIS build's ClwithTime (time_mlp.0.*, mod_emb.weight, layers.{0,2,4}.*);
+    `salt` distinguishes the networks of a cl_g dict."""
+    sd = m.state_dict()
+    new = {k: torch.from_numpy(np.asarray(synth.fill(f"{salt}.{k}", v.shape))).to(v.dtype).reshape(v.shape) for k, v in sd.items()}
+    m.load_state_dict(new)
+    return m.eval()
+
+
+def guidance_cases():
+    for n in ("torchvision.transforms", "torchvision.utils", "torchvision.datasets", "matplotlib", "matplotlib.pyplot", "pytorch_fid",
+              "pytorch_fid.fid_score", "PIL", "PIL.Image"):
+        sys.modules.setdefault(n, _Inert(n))
+    for n in ("jax", "jax.numpy", "torchvision", "torchvision.models"):
+        sys.modules[n] = _Inert(n)
+    import lat_sm2_model as LM  # (reference)
+    C2, C3 = _clwithtime_classes()
+    LM.ClwithTime2, LM.ClwithTime3 = C2, C3
+    import train_poly_unet_cont as TP  # (reference script module: its own em_predictor / corrector)
+    torch.set_grad_enabled(False)
+    out = {}
+    # ---- the networks alone: forward and d mean / d x
+    for tag, cls, sz, nc, ids in (("cl2_s64", C2, 64, 1, None), ("cl3_s64", C3, 64, 1, (0, 2)), ("cl2_s256c3", C2, 256, 3, None)):
+        m = _fill_clg(cls(n_mod=2, size_z=sz, n_class=nc), tag)
+        x = inp(f"clg.{tag}.x", (5, 2 * sz)); t = np.linspace(1.0, 1e-3, 5).astype(np.float32)
+        with torch.enable_grad():
+            xt = torch.from_numpy(x).requires_grad_(True)
+            y = m(xt, torch.from_numpy(t)) if ids is None else m(xt, torch.from_numpy(t), *ids)
+            g = torch.autograd.grad(y.mean(), xt)[0]
+        out[f"{tag}_x"], out[f"{tag}_t"], out[f"{tag}_y"], out[f"{tag}_g"] = x, t, y.detach().numpy(), g.numpy()
+    # ---- sde_helper2 (CelebA form): em_predictor / corrector with a cl_g dict over three modalities
+    B, shape = 4, (4, 3, 8, 8)
+    cl = {k: _fill_clg(C2(n_mod=2, size_z=64, n_class=1), "clg" + k) for k in ("01", "02", "12")}
+    x = inp("clg.s.x", shape); score = inp("clg.s.score", shape); noise = inp("clg.s.noise", shape)
+    sde = S.VPSDE(0.1, 20.0, 1000)
+    vt = torch.ones(B) * 0.37
+    cl_s = 2000.0
+    for given in ("0", "02", "12"):
+        orig = torch.randn_like
+        torch.randn_like = lambda _x: torch.from_numpy(noise)
+        try:
+            xn, xm = S.em_predictor(torch.from_numpy(x), vt, lambda a, b: torch.from_numpy(score).clone(), sde, cl_g=cl, cl_s=cl_s, given=given, all_mods="012")
+            cn, cm = S.corrector(torch.from_numpy(x), vt, lambda a, b: torch.from_numpy(score).clone(), sde, 1, 0.16, cl_g=cl, cl_s=cl_s, given=given, all_mods="012")
+        finally:
+            torch.randn_like = orig
+        out[f"s_{given}_em_x"], out[f"s_{given}_em_mean"], out[f"s_{given}_co_x"], out[f"s_{given}_co_mean"] = xn.numpy(), xm.numpy(), cn.numpy(), cm.numpy()
+    out["s_x"], out["s_score"], out["s_noise"], out["s_t"], out["s_cl_s"] = x, score, noise, vt.numpy(), np.float32(cl_s)
+    # unguided, to show the fixtures are sensitive to the guidance term
+    orig = torch.randn_like
+    torch.randn_like = lambda _x: torch.from_numpy(noise)
+    try:
+        out["s_none_em_mean"] = S.em_predictor(torch.from_numpy(x), vt, lambda a, b: torch.from_numpy(score).clone(), sde)[1].numpy()
+    finally:
+        torch.randn_like = orig
+    print("guidance effect on x_mean:", float(np.abs(out["s_0_em_mean"] - out["s_none_em_mean"]).max()), "of", float(np.abs(out["s_none_em_mean"]).max()))
+    # ---- train_poly_unet_cont (PolyMNIST form): ONE random (given, predicted) pair per call, ids passed, predicted score only
+    cl3 = _fill_clg(C3(n_mod=2, size_z=64, n_class=1), "clgpoly")
+    shape = (4, 4, 8, 8)
+    x = inp("clg.p.x", shape); score = inp("clg.p.score", shape); noise = inp("clg.p.noise", shape)
+    for k, seed in enumerate((11, 12, 13)):
+        orig = torch.randn_like
+        torch.randn_like = lambda _x: torch.from_numpy(noise)
+        try:
+            torch.manual_seed(seed)
+            xn, xm = TP.em_predictor(torch.from_numpy(x), vt, lambda a, b: torch.from_numpy(score).clone(), 0.1, 5.0, 100, False, cl3, cl_s, None, given="02", all_mods="0123")
+            torch.manual_seed(seed)
+            cn, cm = TP.corrector(torch.from_numpy(x), vt, lambda a, b: torch.from_numpy(score).clone(), 0.1, 5.0, 100, 1, 1, 0.16, cl3, cl_s, None, given="02", all_mods="0123")
+        finally:
+            torch.randn_like = orig
+        out[f"p_{k}_em_mean"], out[f"p_{k}_em_x"], out[f"p_{k}_co_mean"], out[f"p_{k}_co_x"] = xm.numpy(), xn.numpy(), cm.numpy(), cn.numpy()
+        out[f"p_{k}_seed"] = np.int64(seed)
+    out["p_x"], out["p_score"], out["p_noise"] = x, score, noise
+    save("guidance.npz", **out)
+
+
+if __name__ == "__main__" and "guid" in sys.argv[1:]:
+    guidance_cases()
+
+
+# ---------------------------------------------------------------------------------------------
+# CelebA conditional loops from the reference's OWN script functions, called unmodified:
+#   train_lat_celebhq_unet_cont2.calc_perf  (:240-373; the loop under test :286-316: per-step re-noising of the given modalities,
+#       re-assembly, em_predictor [+ corrector], write-back of the predicted slices, final z_mean)
+#   eval_lat_celeba_hq_all.evaluate         (:211-343; the loop under test :258-275: 500-level annealed Langevin with per-modality
+#       er[mod], c[mod])
+# The (V)AEs are stand-ins that hand out fixed latents and record what they are asked to decode (the real decoders are pinned in
+# decoders.npz); the score nets are real reference Unets; sinks (save_batch_image, FID, f1_score) are replaced by no-ops.
+class _FakeVAE:
+    def __init__(self, mu, out_shape):
+        self.mu, self.out_shape, self.decoded = mu, out_shape, []
+
+    def eval(self):
+        return self
+
+    def encoder(self, x):
+        return (torch.from_numpy(self.mu), torch.zeros_like(torch.from_numpy(self.mu)))
+
+    def decoder(self, z):
+        self.decoded.append(z.detach().numpy().copy())
+        return torch.zeros(self.out_shape)
+
+
+def celeba_cond_cases():
+    for n in ("torchvision.transforms", "torchvision.utils", "torchvision.datasets", "matplotlib", "matplotlib.pyplot", "pytorch_fid",
+              "pytorch_fid.fid_score", "PIL", "PIL.Image", "celeba_hq_mask_dataset", "mopoe_model", "mmplus_model_cel", "sklearn", "sklearn.metrics"):
+        sys.modules.setdefault(n, _Inert(n))
+    for n in ("jax", "jax.numpy", "torchvision", "torchvision.models"):
+        sys.modules[n] = _Inert(n)
+    import lat_sm2_model as LM  # (reference)
+    C2, C3 = _clwithtime_classes()
+    LM.ClwithTime2, LM.ClwithTime3 = C2, C3
+    cvd = os.environ.get("CUDA_VISIBLE_DEVICES")
+    import train_lat_celebhq_unet_cont2 as TC  # (reference script module)
+    import eval_lat_celeba_hq_all as E  # (reference script module)
+    if cvd is None:
+        os.environ.pop("CUDA_VISIBLE_DEVICES", None)
+    for mod in (TC, E):
+        mod.save_batch_image = lambda *a, **k: None
+        mod.calculate_fid_given_paths = lambda *a, **k: 0.0
+        mod.f1_score = lambda *a, **k: 0.0
+    out = {}
+    B, size_z, N = 3, 64, 20
+    images, masks = torch.zeros(B, 3, 8, 8), torch.zeros(B, 1, 8, 8)
+    target = torch.zeros(B, 18)
+    attr_visible = list(range(18))
+    mus = [inp(f"celcond.mu{k}", (B, size_z)) for k in range(3)]
+    path = {"in_image": "x/", "out_image_vae": "x/", "out_image_ae": "x/"}
+    score = synth.fill_module_(Unet(dim=16, channels=3, dim_mults=(1, 2, 2, 2)).eval())
+    for k in range(3):
+        out[f"mu{k}"] = mus[k]
+    # ---- calc_perf
+    for tag, given, noise_obs, pc in (("g0_n1_pc1", "0", True, True), ("g12_n1_pc0", "12", True, False), ("g02_n0_pc1", "02", False, True), ("gnone_pc0", "", False, False)):
+        vaes = [_FakeVAE(mus[0], (B, 3, 8, 8)), _FakeVAE(mus[1], (B, 1, 8, 8)), _FakeVAE(mus[2], (B, 18))]
+        sde = S.VPSDE(0.1, 5.0, N)
+        with _Noise(0xCE1 + len(out)) as nz:
+            TC.calc_perf([(images, masks, target)], vaes[0], vaes[1], vaes[2], attr_visible, 0.5, 3, score, "cpu", sde, size_z, given, path,
+                         eps=1e-3, noise_obs=noise_obs, vae_type="VAE", pc=pc, n_steps=1, target_snr=0.16)
+        for k in range(3):
+            out[f"cp_{tag}_z{k}"] = vaes[k].decoded[-1]                 # the latents handed to the final decode (:318-319)
+        out[f"cp_{tag}_seed"] = np.asarray([nz.seed, len(nz.log)])
+        kinds = [kk for kk, _ in nz.log]
+        n_prior = sum(1 for m in "012" if m not in given)
+        assert kinds[:n_prior] == ["randn"] * n_prior and len(kinds) == n_prior + N * (2 if pc else 1), kinds
+        print("calc_perf", tag, "draws", len(nz.log), "|z| max", max(float(np.abs(out[f"cp_{tag}_z{k}"]).max()) for k in range(3)))
+    # ---- eval_lat_celeba_hq_all.evaluate: per-modality er / c (values of the script's own table :459-513 for 'VAE')
+    tame = _Tamed(synth.fill_module_(Unet(dim=8, channels=3, dim_mults=(1, 2, 2, 2)).eval()))
+    er = {"0": 2e-3, "1": 1e-3, "2": 3e-3}
+    cc = {"0": 0.5, "1": 0.4, "2": 0.7}
+    for tag, given in (("g0", "0"), ("g12", "12"), ("gnone", "")):
+        vaes = [_FakeVAE(mus[0], (B, 3, 8, 8)), _FakeVAE(mus[1], (B, 1, 8, 8)), _FakeVAE(mus[2], (B, 18))]
+        spy = _Spy(tame, (0, 1, 2, 999))
+        with _Noise(0xCE2 + len(out)) as nz:
+            E.evaluate([(images, masks, target)], vaes[0], vaes[1], vaes[2], attr_visible, 0.5, 3, spy, _Inert("difvae"), "cpu", size_z, er, 2, given, path, cc, is_vae=True)
+        for k in range(3):
+            out[f"ev_{tag}_z{k}"] = vaes[k].decoded[-1] if str(k) not in given else mus[k]
+        out[f"ev_{tag}_seed"] = np.asarray([nz.seed, len(nz.log)])
+        for k2, v in spy.seen.items():
+            out[f"ev_{tag}_zin{k2}"] = v
+        print("evaluate", tag, "score calls", spy.calls, "draws", len(nz.log), "|z| max", max(float(np.abs(out[f"ev_{tag}_z{k}"]).max()) for k in range(3)))
+    out["ev_er"] = np.asarray([er[m] for m in "012"]); out["ev_c"] = np.asarray([cc[m] for m in "012"])
+    save("celeba_cond.npz", **out)
+
+
+if __name__ == "__main__" and "celcond" in sys.argv[1:]:
+    celeba_cond_cases()

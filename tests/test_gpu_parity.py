@@ -304,7 +304,7 @@ def test_c_abi_error_paths(pkg):
     L = pkg["lib"]
     lib = L.lib()
     cfg = L.SdeCfg(0, 0.1, 5.0, 100, 0.16, 0)
-    rc = lib.sbm_em_step(ctypes.byref(cfg), None, None, None, None, None, None, 4, 128, 0, 0, 0, None)
+    rc = lib.sbm_em_step(ctypes.byref(cfg), None, None, None, None, None, None, 4, 128, 0, 0, 0, 0, None)
     assert rc != 0 and b"bad arguments" in lib.sbm_last_error()
     with pytest.raises(RuntimeError):
         L.Engine(0, L.unet_cfg_ints(8, 2, (1, 2, 2, 2, 2, 2), 8, 8), 2,
