@@ -1,22 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- samples/sec of the latent score-model sampling path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {2,4,5}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]/[2]): PolyMNIST 5-modality unconditional sampling, 1000-step reverse
-SDE (VPSDE beta=(0.1,5), Euler-Maruyama predictor, pc=False), Unet(64, ch=5, (1,2,2,2)) score net over the
-(B,5,8,8) joint latent, then the five ResVAE decoders -> (B,3,32,32) images; batch 256 per GPU,
-sharded over N GPUs (weak scaling) with ONE all-gather of the decoded images at the end.
+Workloads (BASELINE.json `configs`).  Default = config 2 (configs[1], and configs[2] when N > 1):
+  2  PolyMNIST 5-modality unconditional sampling, 1000-step reverse SDE (VPSDE beta=(0.1,5), Euler-Maruyama predictor, pc=False),
+     Unet(64, ch=5, (1,2,2,2)) over the (B,5,8,8) joint latent, then the five ResVAE decoders -> (B,3,32,32); batch 256 per GPU
+  4  CelebAMaskHQ 3-modality: Unet(256, ch=3, (1,2,2,2,2)) over (B,3,16,16) latents, VPSDE beta=(0.1,20), 1000 steps, then the
+     ResVAEN image / mask decoders (128x128) and the CelebAAttrNewBN attribute decoder; batch 64 per GPU
+  5  CelebAMaskHQ conditional: UNetModel(3,128,3,2,(),0.1,(1,2,4,8),use_z,z_dim=512) with z_cond ~ N(0,I), otherwise as 4
+each sharded over N GPUs by batch (weak scaling) through distributed.sample_sharded: ONE all-gather of the decoded outputs.
 
-A "step" is one full pass of that path over one batch (prior -> 1000 SDE steps -> 5 decoders ->
-gather).  Inputs (weights, prior) are resident in HBM before the timed region; the in-loop noise is
-drawn in-kernel (Philox).  Rank 0 prints ONE JSON line.
+A "step" is one full pass of that path over one batch (prior -> 1000 SDE steps -> decoders -> gather).  Inputs (weights, prior,
+z_cond) are resident in HBM before the timed region; the in-loop noise is drawn in-kernel (Philox).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,8 +32,16 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-N_MOD, N_SDE, B_PER_GPU = 5, 1000, 256
-BETA = (0.1, 5.0)
+N_SDE = 1000
+# per-sample dense-convention FLOP: score eval, decoders
+WORK = {
+    2: dict(name="PolyMNIST 5-modality, 1000-step reverse SDE (VPSDE EM predictor, pc=False), batch 256 per GPU, Unet(64,ch=5,(1,2,2,2)) + 5 ResVAE decoders -> 32x32 images",
+            B=256, n_mod=5, hw=8, beta=(0.1, 5.0), score_flop=158_055_936, dec_flop=5 * 243_662_848),
+    4: dict(name="CelebAMaskHQ 3-modality, 1000-step reverse SDE (VPSDE EM predictor, pc=False), batch 64 per GPU, Unet(256,ch=3,(1,2,2,2,2)) on 16x16 latents + ResVAEN image/mask + CelebAAttrNewBN decoders",
+            B=64, n_mod=3, hw=16, beta=(0.1, 20.0), score_flop=9_349_614_848, dec_flop=8_277_000_000 + 3_064_000_000 + 1_600_000),
+    5: dict(name="CelebAMaskHQ conditional, 1000-step reverse SDE (VPSDE EM predictor, pc=False), batch 64 per GPU, UNetModel(3,128,3,2,(),0.1,(1,2,4,8),use_z,z_dim=512)+z_cond on 16x16 latents + the CelebA decoders",
+            B=64, n_mod=3, hw=16, beta=(0.1, 20.0), score_flop=5_467_734_016, dec_flop=8_277_000_000 + 3_064_000_000 + 1_600_000),
+}
 
 
 def log(msg):
@@ -67,56 +79,146 @@ def host_cores():
     return int(os.environ.get("SBM_CPU_THREADS", n))
 
 
-def build_models(device):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def lib_hash():
+    from score_based_multimodal_autoencoder_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib.LIB_PATH, "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_models(cfg, device):
+    """Score net + decoders of the workload with the closed-form filler weights (no checkpoints exist)."""
     from score_based_multimodal_autoencoder_amd import arch, synth
-    from score_based_multimodal_autoencoder_amd.h_vae_model_copy import ResVAE
+    from score_based_multimodal_autoencoder_amd.h_vae_model import CelebAAttrNewBN
+    from score_based_multimodal_autoencoder_amd.h_vae_model_copy import ResVAE, ResVAEN
     from score_based_multimodal_autoencoder_amd.unet_model import Unet
-    score = synth.fill_module_(Unet(dim=64, channels=N_MOD, dim_mults=(1, 2, 2, 2)).eval()).to(device)
-    # one decoder per modality; synthetic weights (same closed-form filler for each: no checkpoints exist)
-    decs = [synth.fill_module_(ResVAE(arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3).eval()).to(device) for _ in range(N_MOD)]
+    from score_based_multimodal_autoencoder_amd.unet_openai import UNetModel
+    if cfg == 2:
+        score = Unet(dim=64, channels=5, dim_mults=(1, 2, 2, 2))
+        decs = [ResVAE(arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3) for _ in range(5)]
+    else:
+        score = Unet(dim=256, channels=3, dim_mults=(1, 2, 2, 2, 2)) if cfg == 4 else \
+            UNetModel(3, 128, 3, 2, (), 0.1, (1, 2, 4, 8), num_heads=1, use_z=True, z_dim=512)
+        decs = [ResVAEN(arch.CEL_IMG_ENC, arch.CEL_IMG_DEC, 128, 256, 3), ResVAEN(arch.CEL_MASK_ENC, arch.CEL_MASK_DEC, 128, 256, 1), CelebAAttrNewBN(256)]
+    score = synth.fill_module_(score.eval()).to(device)
+    decs = [synth.fill_module_(d.eval()).to(device) for d in decs]
     return score, decs
 
 
-def one_pass(score, decs, sde, x0, seed, start, device, timing=False):
+def one_pass(cfg, score, decs, sde, x0, zc, seed, start, device, timing=False):
+    """prior -> N-step sampler -> decoders on this rank's rows [start, start + B)."""
     from score_based_multimodal_autoencoder_amd.sde_helper2 import uncond_sampler
+    W = WORK[cfg]
     B = x0.shape[0]
-    r = uncond_sampler((B, N_MOD, 8, 8), score, device, sde, x0=x0, seed=seed, sample_offset=start, return_timing=timing)
+    kw = {} if zc is None else {"z_cond": zc}
+    r = uncond_sampler((B, W["n_mod"], W["hw"], W["hw"]), score, device, sde, x0=x0, seed=seed, sample_offset=start, return_timing=timing, **kw)
     z, ms = (r if timing else (r, None))
-    imgs = [decs[i].decoder(z[:, i, :, :].view(B, 64)) for i in range(N_MOD)]        # train_poly_unet_cont.py:302-303
-    return z, imgs, ms
+    sz = W["hw"] * W["hw"]
+    outs = [decs[i].decoder(z[:, i, :, :].view(B, sz)) for i in range(W["n_mod"])]       # train_poly_unet_cont.py:302-303 / train_lat_celebhq_unet_cont2.py:318-319
+    return z, outs, ms
 
 
-def cpu_baseline(n_steps=10):
-    """The reference's CPU path on the host cores: oracle/torch_port.py (same ATen operator sequence as the
-    reference on CPU), B=256, n_steps SDE steps + the 5 decoders, extrapolated linearly to 1000 steps."""
+def cpu_baseline(cfg, reps=3, n_steps=20):
+    """The reference's CPU path on the host cores: oracle/torch_port.py (the ATen operator sequence the reference executes on a CPU),
+    `reps` repetitions of `n_steps` SDE steps at the workload's batch (median), + the decoders once, extrapolated linearly to
+    N = 1000 (steps are identical work).  Config 2 additionally times BASELINE config 1 (2-mod, B=16, N=100) in full."""
     from oracle import torch_port as TP
     from score_based_multimodal_autoencoder_amd import arch, synth
     cores = host_cores()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline: {cores} threads, {n_steps} SDE steps at B={B_PER_GPU}")
-    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(
-        arch.unet_state_shapes(dim=64, channels=N_MOD, dim_mults=(1, 2, 2, 2))).items()}
-    dsd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(
-        arch.resvae_state_shapes("ResVAE", arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3)).items()}
-    x = torch.from_numpy(synth.noise(0, 0, (B_PER_GPU, N_MOD, 8, 8)))
-    ts = torch.linspace(1.0, 1e-3, N_SDE)
+    W = WORK[cfg]
+
+    def sd_of(shapes):
+        return {k: torch.from_numpy(np.asarray(v)) for k, v in synth.fill_state_dict(shapes).items()}
+
+    out = {"unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model()}
     with torch.no_grad():
-        TP.unet_forward(sd, x, torch.ones(B_PER_GPU) * ts[0], 64, 4)                  # warm-up
-        t0 = time.perf_counter()
-        for i in range(n_steps):
-            vt = torch.ones(B_PER_GPU) * ts[i]
-            z = torch.randn_like(x)
-            s = TP.unet_forward(sd, x, vt, 64, 4)
-            x, xm = TP.vp_em_step(x, vt, s, z, BETA[0], BETA[1], N_SDE)
-        t_step = (time.perf_counter() - t0) / n_steps
-        t0 = time.perf_counter()
-        for i in range(N_MOD):
-            TP.poly_decoder(dsd, xm[:, i].reshape(B_PER_GPU, 64), arch.POLY_DEC)
-        t_dec = time.perf_counter() - t0
-    total = N_SDE * t_step + t_dec
-    return {"value": B_PER_GPU / total, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/torch_port.py (ATen CPU ops = the reference's CPU path), B={B_PER_GPU}, {n_steps} of {N_SDE} "
-                      f"SDE steps ({t_step * 1e3:.1f} ms/step) + 5 decoders ({t_dec:.2f} s), extrapolated linearly"}
+        if cfg == 2:
+            B = W["B"]
+            sd = sd_of(arch.unet_state_shapes(dim=64, channels=5, dim_mults=(1, 2, 2, 2)))
+            dsd = sd_of(arch.resvae_state_shapes("ResVAE", arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3))
+            fwd = lambda x, vt: TP.unet_forward(sd, x, vt, 64, 4)
+            dec = lambda xm: [TP.poly_decoder(dsd, xm[:, i].reshape(B, 64), arch.POLY_DEC) for i in range(5)]
+        elif cfg == 4:
+            B = 8                                                    # bounded sample: 1/8 of the batch, scaled linearly
+            sd = sd_of(arch.unet_state_shapes(dim=256, channels=3, dim_mults=(1, 2, 2, 2, 2)))
+            fwd = lambda x, vt: TP.unet_forward(sd, x, vt, 256, 5)
+            dec = None
+        else:
+            B = 8
+            kw = dict(in_channels=3, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(), channel_mult=(1, 2, 4, 8), z_dim=512, use_z=True)
+            sd = sd_of(dict(arch.unet_openai_entries(**kw)))
+            zc = torch.from_numpy(synth.noise(3, 0, (B, 512)))
+            fwd = lambda x, vt: TP.unet_openai_forward(sd, x, vt, zc)
+            dec = None
+        x = torch.from_numpy(synth.noise(0, 0, (B, W["n_mod"], W["hw"], W["hw"])))
+        ts = torch.linspace(1.0, 1e-3, N_SDE)
+        if cfg != 2:
+            n_steps, reps = 3, 3
+        log(f"cpu_baseline: {cores} threads ({out['cpu_model']}), {reps} x {n_steps} SDE steps at B={B}")
+        fwd(x, torch.ones(B) * ts[0])                                                  # warm-up
+        per_step = []
+        for r in range(reps):
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                vt = torch.ones(B) * ts[i]
+                z = torch.randn_like(x)
+                s = fwd(x, vt)
+                x, xm = TP.vp_em_step(x, vt, s, z, W["beta"][0], W["beta"][1], N_SDE)
+            per_step.append((time.perf_counter() - t0) / n_steps)
+        t_step = statistics.median(per_step)
+        t_dec = 0.0
+        if dec is not None:
+            t0 = time.perf_counter()
+            dec(xm)
+            t_dec = time.perf_counter() - t0
+        total = N_SDE * t_step + t_dec
+        out["value"] = B / total
+        out["sample"] = (f"oracle/torch_port.py (ATen CPU ops = the reference's CPU path), B={B}" + (f" of {W['B']} (per-sample cost scaled linearly)" if B != W["B"] else "") +
+                         f", median of {reps} x {n_steps} of {N_SDE} SDE steps ({t_step * 1e3:.1f} ms/step; all: {[round(p * 1e3, 1) for p in per_step]})" +
+                         (f" + the decoders ({t_dec:.2f} s)" if dec is not None else " (decoders not timed: < 1 % of the pass)") + ", extrapolated linearly to 1000 steps")
+        if cfg == 2:
+            # BASELINE configs[0], in full: 2-mod, 32x32 images, 100-step EM, batch 16 (the reference's own CPU-runnable case)
+            sd1 = sd_of(arch.unet_state_shapes(dim=64, channels=2, dim_mults=(1, 2, 2, 2)))
+            x1 = torch.from_numpy(synth.noise(1, 0, (16, 2, 8, 8)))
+            ts1 = torch.linspace(1.0, 1e-3, 100)
+            t0 = time.perf_counter()
+            for i in range(100):
+                vt = torch.ones(16) * ts1[i]
+                s = TP.unet_forward(sd1, x1, vt, 64, 4)
+                x1, xm1 = TP.vp_em_step(x1, vt, s, torch.randn_like(x1), 0.1, 5.0, 100)
+            for i in range(2):
+                TP.poly_decoder(dsd, xm1[:, i].reshape(16, 64), arch.POLY_DEC)
+            t1 = time.perf_counter() - t0
+            out["config1_full"] = {"value": 16 / t1, "unit": "samples/s", "seconds": t1,
+                                   "sample": "BASELINE configs[0] in full: 2-modality, 100-step EM, batch 16, + 2 decoders"}
+    return out
+
+
+def committed_profile(name):
+    """A committed rocprofv3 summary of THIS build (profiles/<name>), or None when its recorded library hash is not the hash of the
+    library this run loaded (the kernels changed since it was taken: the number would be stale)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as fh:
+            j = json.load(fh)
+    except Exception as exc:
+        log(f"no {name}: {exc}")
+        return None
+    if j.get("lib_hash") != lib_hash():
+        log(f"{name} was taken with library {j.get('lib_hash')}, this run loads {lib_hash()}: not used")
+        return None
+    return j
 
 
 def main():
@@ -124,34 +226,42 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
+    cfg = args.config
+    W = WORK[cfg]
+    B = W["B"]
 
     from score_based_multimodal_autoencoder_amd import distributed as D
     from score_based_multimodal_autoencoder_amd.sde_helper2 import VPSDE
     rank, world = D.init_from_env("nccl") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
-    if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
-    from score_based_multimodal_autoencoder_amd import _lib as _L
-    if not os.path.exists(_L.LIB_PATH):          # the in-tree library normally travels with the tree; compile it (hipcc, gfx950) if it did not
+    from score_based_multimodal_autoencoder_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):          # the in-tree library normally travels with the tree; compile it (hipcc, gfx950) if it did not
         if local == 0:
-            _L.build(verbose=True)
+            _lib.build(verbose=True)
         if world > 1:
             torch.distributed.barrier()
-    log(f"rank {rank}/{world}: building models")
-    score, decs = build_models(device)
-    sde = VPSDE(BETA[0], BETA[1], N_SDE)
-    start = rank * B_PER_GPU
-    from score_based_multimodal_autoencoder_amd import _lib
-    # prior resident in HBM before the timed region (Philox, keyed by the global sample index)
-    x0 = torch.empty((B_PER_GPU, N_MOD, 8, 8), device=device)
-    _lib.check(_lib.lib().sbm_fill_normal(x0.data_ptr(), N_MOD * 64, B_PER_GPU, 1234, start, 0, 255, 1.0, None))
+    log(f"rank {rank}/{world}: building models for config {cfg}")
+    score, decs = build_models(cfg, device)
+    sde = VPSDE(W["beta"][0], W["beta"][1], N_SDE)
+    start = rank * B
+    chw = W["n_mod"] * W["hw"] * W["hw"]
+    # prior (and z_cond) resident in HBM before the timed region (Philox, keyed by the global sample index)
+    x0 = torch.empty((B, W["n_mod"], W["hw"], W["hw"]), device=device)
+    _lib.check(_lib.lib().sbm_fill_normal(x0.data_ptr(), chw, B, 1234, start, 0, 255, 1.0, None))
+    zc = None
+    if cfg == 5:
+        zc = torch.empty((B, 512), device=device)
+        _lib.check(_lib.lib().sbm_fill_normal(zc.data_ptr(), 512, B, 1235, start, 0, 254, 1.0, None))
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,9 +270,12 @@ def main():
         torch.cuda.synchronize()
 
     def job(seed):
-        z, imgs, _ = one_pass(score, decs, sde, x0, seed, start, device)
-        flat = torch.cat([i.reshape(B_PER_GPU, -1) for i in imgs], dim=1)
-        return D.all_gather_cat(flat)                 # the single collective (RCCL all-gather over xGMI)
+        # the gloo-tested helper IS the benched path: this rank's rows, then ONE all-gather (RCCL over xGMI) of the packed outputs
+        def sample_fn(first, count):
+            assert first == start and count == B
+            _, outs, _ = one_pass(cfg, score, decs, sde, x0, zc, seed, first, device)
+            return tuple(outs)
+        return D.sample_sharded(sample_fn, world * B)
 
     for w in range(args.warmup):
         job(100 + w)
@@ -177,65 +290,79 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    assert torch.isfinite(out).all()
+    assert all(torch.isfinite(o).all() for o in out) and out[0].shape[0] == world * B
     log(f"timed {args.steps} passes in {elapsed:.3f} s")
 
     if rank == 0:
-        value = world * B_PER_GPU * args.steps / elapsed
+        value = world * B * args.steps / elapsed
+        flop_per_sample = W["score_flop"] * N_SDE + W["dec_flop"]
         line = {
-            "metric": "samples/sec (1000-step reverse SDE, PolyMNIST 5-mod)", "value": value, "unit": "samples/s",
+            "metric": "samples/sec (1000-step reverse SDE, PolyMNIST 5-mod)" if cfg == 2 else f"samples/sec (1000-step reverse SDE, BASELINE config {cfg})",
+            "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PolyMNIST 5-modality, 1000-step reverse SDE (VPSDE EM predictor, pc=False), "
-                                   "batch 256 per GPU, Unet(64,ch=5,(1,2,2,2)) + 5 ResVAE decoders -> 32x32 images",
-                       "global_batch": world * B_PER_GPU, "sde_steps": N_SDE, "parallelism": f"batch-shard x{world}, 1 all-gather"},
+            "config": {"workload": W["name"], "baseline_config": cfg, "global_batch": world * B, "sde_steps": N_SDE,
+                       "parallelism": f"batch-shard x{world}, 1 all-gather"},
         }
-        # ---- roofline of the dominant kernel (seg_gemm), measured live with HIP events on its stream ----
-        eng = score._engine_for(B_PER_GPU, 8, 8)
+        # ---- roofline of the dominant GEMM kernel, measured live with HIP events riding on each kernel's own dispatch ----
+        eng = score._engine_for(B, W["hw"], W["hw"]) if cfg != 5 else score._engine_for(B, W["hw"], W["hw"], True)
         xs = x0.clone()
-        tt = torch.ones(B_PER_GPU, device=device) * 0.5
+        tt = torch.ones(B, device=device) * 0.5
         so = torch.empty_like(xs)
-        prof = eng.profile(xs, tt, so, reps=20, sampler_mix=True)      # the launches one SDE step of the timed loop makes
+        if cfg == 5:
+            _lib.check(_lib.lib().sbm_model_set_aux(eng.h, zc.data_ptr()))
+            eng.forward_aux(xs, tt, zc, so)
+        prof = eng.profile(xs, tt, so, reps=20 if cfg == 2 else 5, sampler_mix=True)      # the launches one SDE step of the timed loop makes
         log("per-kernel profile done")
         f_seg, f_chain = eng.gemm_flops(sampler_mix=True)
         kern = {}
-        for name, label, fl in (("seg_gemm", "seg_gemm<BM,BN> (fp32 MFMA implicit-GEMM conv, one launch per 8x8 layer)", f_seg),
+        for name, label, fl in (("seg_gemm", "seg_gemm<BM,BN> (fp32 MFMA implicit-GEMM conv, one launch per layer)", f_seg),
                                 ("chain_kernel", "chain_kernel (XCD-resident run of the 4x4/2x2/1x1 layers: fp32 MFMA GEMMs + dwconv/attention/GroupNorm glue)", f_chain)):
             k = prof.get(name, dict(ms=0.0, launches=0))
-            if k["launches"]:
+            if k["launches"] and fl > 0:
                 kern[name] = dict(kernel=label, launches_per_forward=k["launches"], avg_launch_us=1e3 * k["ms"] / k["launches"], ms_per_forward=k["ms"],
                                   dense_gemm_flop_per_forward=fl, achieved=fl / (k["ms"] * 1e-3) / 1e12)
         dom = max(kern, key=lambda n: kern[n]["ms_per_forward"])
-        # HBM-side traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs of
-        # tools/traffic_probe.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; unit KB)
-        traffic = None
-        try:
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")) as fh:
-                tj = json.load(fh)
-            rows = [v for k, v in tj.items() if dom in k]
-            fetch = sum(r["FETCH_SIZE"]["avg_per_launch_raw"] * r["FETCH_SIZE"]["launches"] for r in rows)
-            write = sum(r["WRITE_SIZE"]["avg_per_launch_raw"] * r["WRITE_SIZE"]["launches"] for r in rows)
-            n = sum(r["FETCH_SIZE"]["launches"] for r in rows)
-            traffic = (2.0 * fetch + write) * 1024.0 / n
-        except Exception as exc:                       # the profile file is optional
-            log(f"no PMC traffic summary: {exc}")
-        _, _, loop_ms = one_pass(score, decs, sde, x0, 7, start, device, timing=True)
+        # HBM-side traffic per launch and the matrix pipe's duty cycle from the committed rocprofv3 --pmc passes of THIS library build
+        # (separate FETCH_SIZE / WRITE_SIZE / SQ passes over eager forwards, tools/traffic_probe.py; FETCH_SIZE doubled as
+        # MI355X_MICROARCH.md prescribes for gfx950; unit KB).  Null when the profile was taken with a different build.
+        traffic = mfma_busy = None
+        tag = f"r02_c{cfg}"
+        tj = committed_profile(f"{tag}_traffic.json")
+        if tj:
+            rows = [v for k, v in tj["kernels"].items() if dom in k]
+            if rows:
+                fetch = sum(r["FETCH_SIZE"]["avg_per_launch_raw"] * r["FETCH_SIZE"]["launches"] for r in rows)
+                write = sum(r["WRITE_SIZE"]["avg_per_launch_raw"] * r["WRITE_SIZE"]["launches"] for r in rows)
+                n = sum(r["FETCH_SIZE"]["launches"] for r in rows)
+                traffic = (2.0 * fetch + write) * 1024.0 / n
+        sj = committed_profile(f"{tag}_sq_counters.json")
+        if sj:
+            rows = [v for k, v in sj["kernels"].items() if dom in k and "mfma_busy_frac" in v]
+            if rows:
+                mfma_busy = sum(r["mfma_busy_frac"] * r["GRBM_GUI_ACTIVE"] * r["launches"] for r in rows) / sum(r["GRBM_GUI_ACTIVE"] * r["launches"] for r in rows)
+        _, _, loop_ms = one_pass(cfg, score, decs, sde, x0, zc, 7, start, device, timing=True)
         fwd_ms = sum(v["ms"] for v in prof.values())
         line["roofline"] = {
             "bound": "mfma", "achieved": kern[dom]["achieved"], "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": kern[dom]["achieved"] / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-            "traffic_note": "bytes per launch at the L2's memory side (Infinity-Cache hits included), rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json",
+            "mfma_busy_frac": mfma_busy,
+            "frac_note": "frac = dense-convention GEMM FLOP (zero-padding taps counted, SURVEY 8(d)) / launch time / fp32-MFMA peak; mfma_busy_frac = "
+                         "SQ_VALU_MFMA_BUSY_CYCLES / (launch cycles x 1024 SIMDs): the EXECUTED share (padding taps skipped)",
+            "traffic_note": f"bytes per launch at the L2's memory side (Infinity-Cache hits included), rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/{tag}_traffic.json",
             "kernel": kern[dom]["kernel"], "launches_per_forward": kern[dom]["launches_per_forward"],
             "avg_launch_us": kern[dom]["avg_launch_us"], "dense_flop_per_launch": kern[dom]["dense_gemm_flop_per_forward"] / kern[dom]["launches_per_forward"],
             "gemm_kernels": {n: {k: (round(v, 4) if isinstance(v, float) and k != "dense_gemm_flop_per_forward" else v) for k, v in d.items() if k != "kernel"} for n, d in kern.items()},
             "all_kernels_ms_per_forward": fwd_ms, "loop_ms_per_sde_step": loop_ms / N_SDE,
-            "whole_job_frac_of_fp32_mfma_peak": value / world * (158_055_936 * N_SDE + 5 * 243_662_848) / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
+            "whole_job_frac_of_fp32_mfma_peak": value / world * flop_per_sample / 1e12 / FP32_MATRIX_PEAK_TFLOPS,
             "per_kernel_ms": {k: round(v["ms"], 4) for k, v in prof.items() if v["launches"]},
+            "lib_hash": lib_hash(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_steps)
+            line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_reps, args.cpu_steps)
         print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()                  # rank 0 profiles for a few seconds: nobody tears the group down under it
         torch.distributed.destroy_process_group()
 
 

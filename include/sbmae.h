@@ -9,8 +9,11 @@
  * Conventions: plain pointers and sizes only (no torch types).  All device buffers are fp32,
  * contiguous, 16-byte aligned and owned by the caller.  `stream` is a hipStream_t passed as void*
  * (NULL = the legacy default stream).  All work is enqueued asynchronously on `stream`; nothing
- * synchronises except create/destroy, sbm_sampler_run (when timing is requested) and
- * sbm_model_profile.
+ * synchronises except create/destroy, sbm_model_profile, and sbm_sampler_run / sbm_cond_sampler_run, which run on a PRIVATE stream
+ * of the model handle (ordered after the caller's stream at entry and before it at exit by events) and synchronise that stream
+ * when they replay a captured hipGraph (use_graph, n_run > 1: the graph is released before returning) or when elapsed_ms is
+ * requested.  A chain-kernel barrier that timed out in an earlier call (not every workgroup resident) is reported by the next
+ * sbm_model_forward / sbm_sampler_run on the same handle, without a synchronisation, through a host-mapped flag.
  * Every function returns 0 on success and a non-zero code on failure; sbm_last_error() then
  * returns a message (thread-local).  No C++ exception crosses this boundary.  A model handle is not
  * thread-safe; use one handle per device and per batch size.
@@ -191,6 +194,20 @@ typedef struct sbm_sampler_cfg {
 int sbm_sampler_run(sbm_model* score, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const float* timesteps,
                     const float* alphas, const float* noise, float* x_inout, float* x_mean_out, int first_step,
                     int n_run, float* elapsed_ms, void* stream);
+
+/* The conditional loop of the evaluation callers, fused: per step re-noise (noise_obs) or restore the observed
+ * modalities' latents, then predictor [+ corrector], all captured as ONE step like sbm_sampler_run; at the end the observed channels
+ * of x_mean_out are the clean z_obs.  == the loops of train_lat_celebhq_unet_cont2.calc_perf (:286-316) and
+ * train_poly_unet_cont.evaluate (:356-383), which run predictor -> corrector (cfg->order = 1).
+ *   z_obs: device (B, n_mod, per_mod) -- only the channels in obs_mask are read;  x_inout: the joint state, observed channels ignored. */
+typedef struct sbm_cond_cfg {
+  unsigned obs_mask;    /* bit m set: modality m is observed (given) */
+  int noise_obs;        /* 1: observed latents enter each step as mean(t) z + std(t) z (the reference multiplies std by z itself) */
+  int n_mod;            /* modalities = channels of the joint state */
+} sbm_cond_cfg;
+int sbm_cond_sampler_run(sbm_model* score, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const sbm_cond_cfg* cond, const float* z_obs,
+                         const float* timesteps, const float* alphas, const float* noise, float* x_inout, float* x_mean_out,
+                         int first_step, int n_run, float* elapsed_ms, void* stream);
 
 /* Debug entry points used only by tests/tools: run the first n_ops ops of the plan (synchronises), read back
  * workspace floats, name an op ("<kind>:<reference layer>").  Not part of the drop-in surface. */

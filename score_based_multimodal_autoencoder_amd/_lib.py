@@ -20,7 +20,7 @@ OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "n
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
            "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step", "sbm_langevin_norms", "sbm_langevin_update", "sbm_clg_forward", "sbm_clg_guide",
-           "sbm_fill_normal", "sbm_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
+           "sbm_fill_normal", "sbm_sampler_run", "sbm_cond_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_ctl", "sbm_debug_chain_stamps",
            "sbm_ddpm_step", "sbm_fid_accumulate", "sbm_fid_finalize_stats", "sbm_fid_work_doubles", "sbm_fid_frechet", "sbm_debug_dgemm_tn"]
 
@@ -28,6 +28,10 @@ EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "s
 class SdeCfg(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("b0", ctypes.c_double), ("b1", ctypes.c_double), ("N", ctypes.c_int),
                 ("target_snr", ctypes.c_double), ("probability_flow", ctypes.c_int)]
+
+
+class CondCfg(ctypes.Structure):
+    _fields_ = [("obs_mask", ctypes.c_uint), ("noise_obs", ctypes.c_int), ("n_mod", ctypes.c_int)]
 
 
 class SamplerCfg(ctypes.Structure):
@@ -95,6 +99,8 @@ def lib():
         L.sbm_fill_normal.argtypes = [vp, ctypes.c_long, i, u64, u64, i, i, ctypes.c_float, vp]
         L.sbm_sampler_run.argtypes = [vp, ctypes.POINTER(SdeCfg), ctypes.POINTER(SamplerCfg), vp, vp, vp, vp, vp, i, i,
                                       ctypes.POINTER(ctypes.c_float), vp]
+        L.sbm_cond_sampler_run.argtypes = [vp, ctypes.POINTER(SdeCfg), ctypes.POINTER(SamplerCfg), ctypes.POINTER(CondCfg), vp, vp, vp, vp, vp, vp, i, i,
+                                           ctypes.POINTER(ctypes.c_float), vp]
         L.sbm_debug_forward_partial.argtypes = [vp, vp, vp, vp, i, vp]
         L.sbm_debug_forward_range.argtypes = [vp, vp, vp, vp, i, i, vp]
         L.sbm_debug_workspace_floats.restype = ctypes.c_long

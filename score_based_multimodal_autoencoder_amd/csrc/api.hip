@@ -119,6 +119,9 @@ long sbm_spec(int kind, const int* cfg, int index, char* name, int cap) {
 
 void sbm_model_destroy(sbm_model* m) {
   if (!m) return;
+  // forwards run asynchronously on the CALLER's streams: nothing of this model (workspace, weights, the host-mapped abort word the
+  // chain kernel may still write) may be released under a kernel in flight
+  (void)hipDeviceSynchronize();
   if (m->own) (void)hipStreamSynchronize(m->own);
   if (m->d_params) (void)hipFree(m->d_params);
   if (m->d_ws) (void)hipFree(m->d_ws);
@@ -621,7 +624,7 @@ int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_
 
 // one full sampling step enqueued on `st` (graph-capturable: no allocation, no sync, step index read on device)
 static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sampler_cfg& c, const float* timesteps, const float* alphas, const float* noise,
-                                float* x, float* x_mean, hipStream_t st, bool time_table) {
+                                float* x, float* x_mean, hipStream_t st, bool time_table, const sbm_cond_cfg* cond = nullptr, const float* z_obs = nullptr) {
   const Plan& P = m->plan;
   const int B = P.B, CHW = P.out_C * P.out_H * P.out_W;
   const int dps = 1 + (c.pc ? c.n_steps : 0);
@@ -650,6 +653,13 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
     return nullptr;
   };
   const char* e = nullptr;
+  if (cond) {
+    // conditional loop (train_lat_celebhq_unet_cont2.py:292-303, train_poly_unet_cont.py:356-368): the observed modalities enter every
+    // step as their latents re-noised to level t (noise_obs) or clean; what the previous step wrote there is discarded
+    StepArgs r{};
+    r.x = x; r.x_out = x; r.t = nullptr; r.timesteps = timesteps; r.step_counter = m->d_counter; r.B = B; r.CHW = CHW; r.sde = sp;
+    launch_renoise(r, z_obs, cond->obs_mask, CHW / cond->n_mod, st, cond->noise_obs ? 0 : 1);
+  }
   if (c.order == 0) {                      // sde_helper2.uncond_sampler: corrector, then predictor
     if (c.pc && (e = corrector(0))) return e;
     if ((e = predictor(c.pc ? c.n_steps : 0))) return e;
@@ -661,9 +671,14 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
   return nullptr;
 }
 
-int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const float* timesteps, const float* alphas, const float* noise,
-                    float* x_inout, float* x_mean_out, int first_step, int n_run, float* elapsed_ms, void* stream) {
+static int sampler_run_impl(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const sbm_cond_cfg* cond, const float* z_obs,
+                            const float* timesteps, const float* alphas, const float* noise, float* x_inout, float* x_mean_out, int first_step,
+                            int n_run, float* elapsed_ms, void* stream) {
   if (!m || (m->kind != SBM_UNET && m->kind != SBM_UNET_OA) || !sde || !cfg || !timesteps || !x_inout || !x_mean_out) return fail("sbm_sampler_run: bad arguments");
+  if (cond) {
+    if (!z_obs || cond->n_mod <= 0 || cond->n_mod > 32 || cond->n_mod != m->plan.out_C) return fail("sbm_cond_sampler_run: n_mod must equal the score net's channel count; z_obs must be given");
+    if (((m->plan.out_H * m->plan.out_W)) % 4) return fail("sbm_cond_sampler_run: a modality's latent size must be a multiple of 4");
+  }
   if (m->plan.aux_off >= 0 && !m->aux_persistent) return fail("sbm_sampler_run: the score net was built with z conditioning; call sbm_model_set_aux first");
   m->dp.aux = m->aux_persistent;
   if (!m->plan.needs_time) return fail("sbm_sampler_run: the score net has no time embedding");
@@ -715,7 +730,7 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
   }
   if (cfg->use_graph && n_run > 1) {
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table);
+    e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table, cond, z_obs);
     hipError_t ce = hipStreamEndCapture(st, &graph);
     if (e) return fail(std::string("sbm_sampler_run: ") + e);
     if (ce != hipSuccess) return fail_hip("hipStreamEndCapture", ce);
@@ -724,7 +739,12 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t0, st));
   for (int i = 0; i < n_run; ++i) {
     if (exec) { hipError_t le = hipGraphLaunch(exec, st); if (le != hipSuccess) return fail_hip("hipGraphLaunch", le); }
-    else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table))) return fail(std::string("sbm_sampler_run: ") + e);
+    else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table, cond, z_obs))) return fail(std::string("sbm_sampler_run: ") + e);
+  }
+  if (cond && n_run > 0) {                 // the observed modalities leave as their clean latents (:314-316 keep z[mod] for mod in given)
+    StepArgs r{};
+    r.x = x_mean_out; r.x_out = x_mean_out; r.B = m->plan.B; r.CHW = CHW; r.sde = sp;
+    launch_renoise(r, z_obs, cond->obs_mask, CHW / cond->n_mod, st, 1);
   }
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t1, st));
   if (time_table) { HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st)); guard.armed = false; }      // back to per-forward time inputs
@@ -742,6 +762,18 @@ int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg*
   }
   HIPCHK(hipGetLastError());
   return 0;
+}
+
+int sbm_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const float* timesteps, const float* alphas, const float* noise,
+                    float* x_inout, float* x_mean_out, int first_step, int n_run, float* elapsed_ms, void* stream) {
+  return sampler_run_impl(m, sde, cfg, nullptr, nullptr, timesteps, alphas, noise, x_inout, x_mean_out, first_step, n_run, elapsed_ms, stream);
+}
+
+int sbm_cond_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const sbm_cond_cfg* cond, const float* z_obs,
+                         const float* timesteps, const float* alphas, const float* noise, float* x_inout, float* x_mean_out, int first_step,
+                         int n_run, float* elapsed_ms, void* stream) {
+  if (!cond) return fail("sbm_cond_sampler_run: bad arguments");
+  return sampler_run_impl(m, sde, cfg, cond, z_obs, timesteps, alphas, noise, x_inout, x_mean_out, first_step, n_run, elapsed_ms, stream);
 }
 
 }  // extern "C"

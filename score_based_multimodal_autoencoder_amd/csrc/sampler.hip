@@ -107,14 +107,16 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(const StepArgs a) 
   __shared__ float rs[256], rn[256];
   const int tid = threadIdx.x;
   // batch-mean norms (sde_helper2.py:97-98): every workgroup reduces the B per-sample norms itself
-  float s = 0.f, n = 0.f;
-  for (int i = tid; i < a.B; i += 256) { s += a.norms[2 * i]; n += a.norms[2 * i + 1]; }
-  rs[tid] = s; rn[tid] = n;
-  __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) { if (tid < o) { rs[tid] += rs[tid + o]; rn[tid] += rn[tid + o]; } __syncthreads(); }
-  float gnorm = rs[0] / (float)a.B, nnorm = rn[0] / (float)a.B;
+  float gnorm, nnorm;
   if (a.norm_sums) {       // exact sharded mode: the batch means are over the GLOBAL batch (sums all-reduced by the host side)
     gnorm = (float)(a.norm_sums[0] / (double)a.B_global); nnorm = (float)(a.norm_sums[1] / (double)a.B_global);
+  } else {
+    float s = 0.f, n = 0.f;
+    for (int i = tid; i < a.B; i += 256) { s += a.norms[2 * i]; n += a.norms[2 * i + 1]; }
+    rs[tid] = s; rn[tid] = n;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) { if (tid < o) { rs[tid] += rs[tid + o]; rn[tid] += rn[tid + o]; } __syncthreads(); }
+    gnorm = rs[0] / (float)a.B; nnorm = rn[0] / (float)a.B;
   }
   const long long idx = (long long)blockIdx.x * blockDim.x + tid;
   const int q4 = a.CHW >> 2;
@@ -189,16 +191,17 @@ void launch_ddpm_step(const StepArgs& a, float r, float beta, float s1m, float s
 // Re-noising of the observed modalities in the conditional loop (train_poly_unet_cont.py:356-364,
 // train_lat_celebhq_unet_cont2.py:293-301): x_out[:, c] = mean_coef(t) * z_obs[:, c] + std(t) * z_obs[:, c] for observed c
 // (the reference multiplies std by z itself, not by fresh noise -- reproduced knowingly), x[:, c] otherwise.
-__global__ __launch_bounds__(256) void renoise_kernel(const StepArgs a, const float* z_obs, unsigned obs_mask, int per_mod) {
+__global__ __launch_bounds__(256) void renoise_kernel(const StepArgs a, const float* z_obs, unsigned obs_mask, int per_mod, int plain) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int q4 = a.CHW >> 2;
   if (idx >= (long long)a.B * q4) return;
   const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
   float4 o = *reinterpret_cast<const float4*>(a.x + (long long)b * a.CHW + e);
   if ((obs_mask >> (e / per_mod)) & 1u) {
-    const float t = a.t ? a.t[b] : a.timesteps[a.step_counter ? *a.step_counter : a.step_base];
-    float mc = 1.f, sd;
-    if (a.sde.kind == 2) sd = a.sde.b0 * powf(a.sde.ve_ratio, t);
+    float mc = 1.f, sd = 0.f;
+    const float t = plain ? 0.f : (a.t ? a.t[b] : a.timesteps[a.step_counter ? *a.step_counter : a.step_base]);
+    if (plain) { /* noise_obs off, and the final write-back: the clean observed latent (train_lat_celebhq_unet_cont2.py:300-301) */ }
+    else if (a.sde.kind == 2) sd = a.sde.b0 * powf(a.sde.ve_ratio, t);
     else {
       const float lmc = (-0.25f * (t * t)) * a.sde.b1_minus_b0 - (0.5f * t) * a.sde.b0;     // sde_helper2.py:359
       mc = expf(lmc);
@@ -206,13 +209,14 @@ __global__ __launch_bounds__(256) void renoise_kernel(const StepArgs a, const fl
       sd = a.sde.kind == 0 ? sqrtf(1.0f - e2) : 1.0f - e2;
     }
     const float4 z = *reinterpret_cast<const float4*>(z_obs + (long long)b * a.CHW + e);
-    o.x = mc * z.x + sd * z.x; o.y = mc * z.y + sd * z.y; o.z = mc * z.z + sd * z.z; o.w = mc * z.w + sd * z.w;
+    if (plain) o = z;
+    else { o.x = mc * z.x + sd * z.x; o.y = mc * z.y + sd * z.y; o.z = mc * z.z + sd * z.z; o.w = mc * z.w + sd * z.w; }
   }
   *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
 }
-void launch_renoise(const StepArgs& a, const float* z_obs, unsigned obs_mask, int per_mod, hipStream_t st) {
+void launch_renoise(const StepArgs& a, const float* z_obs, unsigned obs_mask, int per_mod, hipStream_t st, int plain) {
   const long long n = (long long)a.B * (a.CHW >> 2);
-  hipLaunchKernelGGL(renoise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, z_obs, obs_mask, per_mod);
+  hipLaunchKernelGGL(renoise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, z_obs, obs_mask, per_mod, plain);
 }
 
 __global__ void fill_time_kernel(float* t_out, const float* timesteps, const int* step_counter, int B) {

@@ -423,11 +423,18 @@ def renoise_observed(x, z_obs, t, sde, given, out=None):
 
 
 def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target_snr=0.16, noise_obs=False, *, x0=None, noise=None,
-                 z_cond=None):
-    """Conditional generation loop of the training scripts' evaluate() (train_poly_unet_cont.py:340-381,
-    train_lat_celebhq_unet_cont2.py:277-318): channels in `given` hold the observed latents z_obs (re-noised to level t at
+                 z_cond=None, cl_g=None, cl_s=None, all_mods=None, poly_pairs=False, seed=None, sample_offset=0, use_graph=True,
+                 return_timing=False):
+    """Conditional generation loop of the training scripts' evaluators (train_poly_unet_cont.evaluate :340-381,
+    train_lat_celebhq_unet_cont2.calc_perf :277-318): channels in `given` hold the observed latents z_obs (re-noised to level t at
     every step when noise_obs), the others start from N(0,1) (or x0) and follow the reverse SDE, predictor then corrector.
-    Returns the joint state (B, n_mod, H, W): unobserved channels = final x_mean, observed = clean z_obs."""
+    Returns the joint state (B, n_mod, H, W): unobserved channels = final x_mean, observed = clean z_obs.
+
+    With this package's score nets and no guidance the whole loop runs on the device as ONE captured step replayed N times
+    (`sbm_cond_sampler_run`: re-noise + score + predictor [+ corrector] + write-back); otherwise (a generic score callable, or
+    `cl_g` guidance with `all_mods` naming the modalities, e.g. '012') the loop is driven from Python over the same HIP step kernels.
+    noise: injected draws [(N * (1 + pc * n_steps)), B, n_mod, H, W] in execution order (parity tests); default in-kernel Philox
+    (fused) / torch.randn_like (generic)."""
     z_obs = as_f32_cuda(z_obs, "z_obs")
     device = z_obs.device
     B, n_mod = z_obs.shape[0], z_obs.shape[1]
@@ -435,10 +442,43 @@ def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target
     keep = torch.zeros(n_mod, dtype=torch.bool, device=device)
     keep[given] = True
     keep = keep.view(1, n_mod, 1, 1)
+    mask = 0
+    for m in given:
+        mask |= 1 << m
     with torch.no_grad():
         x = (torch.randn_like(z_obs) if x0 is None else as_f32_cuda(x0, "x0")).clone()
         x = torch.where(keep, z_obs, x)
         timesteps = torch.linspace(sde.T, eps, sde.N, device=device)
+        dps = 1 + (n_steps if pc else 0)
+        if noise is not None:
+            noise = as_f32_cuda(noise, "noise")
+            if noise.shape[0] < sde.N * dps:
+                raise ValueError(f"noise needs {sde.N * dps} draws")
+        guided = cl_g is not None and len(given) > 0
+        if _fused_ok(model, z_cond) and not guided:
+            from .unet_openai import UNetModel
+            if isinstance(model, UNetModel):
+                eng = model._engine_for(B, x.shape[2], x.shape[3], z_cond is not None)
+                zc = as_f32_cuda(z_cond, "z_cond") if z_cond is not None else None
+                _lib.check(_lib.lib().sbm_model_set_aux(eng.h, zc.data_ptr() if zc is not None else None))
+            else:
+                eng = model._engine_for(B, x.shape[2], x.shape[3])
+            cfg = sde._cfg(target_snr=target_snr)
+            scfg = _lib.SamplerCfg(int(bool(pc)), int(n_steps), 1, int(bool(use_graph)), fresh_seed(seed), int(sample_offset))
+            ccfg = _lib.CondCfg(mask, int(bool(noise_obs)), n_mod)
+            alphas = _alphas_dev(sde, device) if pc else None
+            x_mean = torch.empty_like(x)
+            ms = ctypes.c_float(0.0)
+            _lib.check(_lib.lib().sbm_cond_sampler_run(eng.h, ctypes.byref(cfg), ctypes.byref(scfg), ctypes.byref(ccfg), z_obs.data_ptr(),
+                                                       timesteps.data_ptr(), alphas.data_ptr() if alphas is not None else None,
+                                                       noise.data_ptr() if noise is not None else None, x.data_ptr(), x_mean.data_ptr(), 0,
+                                                       sde.N, ctypes.byref(ms) if return_timing else None, _lib.stream_ptr()))
+            return (x_mean, ms.value) if return_timing else x_mean
+        gstr = None
+        if guided:
+            if all_mods is None:
+                raise ValueError("guidance needs all_mods (the modality characters of the joint state, e.g. '012')")
+            gstr = "".join(all_mods[m] for m in given)
         x_mean = x
         k = 0
         for i in range(sde.N):
@@ -446,10 +486,12 @@ def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target
             x_in = renoise_observed(x, z_obs, vec_t, sde, given) if noise_obs else torch.where(keep, z_obs, x)
             nz = None if noise is None else noise[k]
             k += 1
-            x_upd, x_mean = em_predictor(x_in, vec_t, model, sde, z_cond=z_cond, noise=nz)
+            x_upd, x_mean = em_predictor(x_in, vec_t, model, sde, cl_g=cl_g, cl_s=cl_s, given=gstr, all_mods=all_mods, z_cond=z_cond, noise=nz,
+                                         poly_pairs=poly_pairs)
             if pc:
                 nzs = None if noise is None else [noise[k + j] for j in range(n_steps)]
                 k += n_steps
-                x_upd, x_mean = corrector(x_upd, vec_t, model, sde, n_steps, target_snr, z_cond=z_cond, noise=nzs)
+                x_upd, x_mean = corrector(x_upd, vec_t, model, sde, n_steps, target_snr, cl_g=cl_g, cl_s=cl_s, given=gstr, all_mods=all_mods,
+                                          z_cond=z_cond, noise=nzs, poly_pairs=poly_pairs)
             x = x_upd
         return torch.where(keep, z_obs, x_mean)

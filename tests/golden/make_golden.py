@@ -788,3 +788,29 @@ def celeba_cond_cases():
 
 if __name__ == "__main__" and "celcond" in sys.argv[1:]:
     celeba_cond_cases()
+
+
+# ---------------------------------------------------------------------------------------------
+# SDE object API that no script calls but the drop-in surface carries: prior_logp, discretize, reverse().sde /
+# .discretize of the real sde_helper2 classes (:236-326, 364-381, 415-421, 457-473).
+def sde_api_cases():
+    out = {}
+    x = inp("sdeapi.x", (4, 2, 8, 8)); sc = inp("sdeapi.score", (4, 2, 8, 8))
+    t = np.array([1.0, 0.5, 0.25, 1e-3], np.float32)
+    out["x"], out["score"], out["t"] = x, sc, t
+    xt, tt = torch.from_numpy(x), torch.from_numpy(t)
+    for tag, sde in (("vp", S.VPSDE(0.1, 20.0, 1000)), ("subvp", S.subVPSDE(0.1, 20.0, 1000)), ("ve", S.VESDE(0.01, 50.0, 1000))):
+        out[f"{tag}_logp"] = sde.prior_logp(xt).numpy()
+        f, G = sde.discretize(xt, tt)
+        out[f"{tag}_disc_f"], out[f"{tag}_disc_G"] = f.numpy(), G.numpy()
+        for pf in (False,):          # probability_flow=True raises inside the reference (0.[:, None, ...]): nothing to pin
+            r = sde.reverse(lambda a, b: torch.from_numpy(sc), pf)
+            d, g = r.sde(xt, tt)
+            out[f"{tag}_rev_drift"], out[f"{tag}_rev_g"] = d.numpy(), g.numpy()
+            rf, rG = r.discretize(xt, tt)
+            out[f"{tag}_rev_disc_f"], out[f"{tag}_rev_disc_G"] = rf.numpy(), rG.numpy()
+    save("sde_api.npz", **out)
+
+
+if __name__ == "__main__" and "sdeapi" in sys.argv[1:]:
+    sde_api_cases()

@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/sbmae.h but not exported"
     assert set(_lib.EXPORTS) <= set(declared)
-    assert L.sbm_abi_version() == 1
+    assert L.sbm_abi_version() == 2
     # the spec tables are host-only: usable without a GPU, and identical to the Python arch tables
     cfg = _lib.unet_cfg_ints(64, 5, (1, 2, 2, 2), 8, 8)
     assert _lib.specs(_lib.SBM_UNET, cfg) == [(k, int(np.prod(s))) for k, s in arch.unet_entries(dim=64, channels=5, dim_mults=(1, 2, 2, 2))]
@@ -103,7 +103,7 @@ def test_sde_objects_scalar_api(golden, kind, b0, b1):
     if kind == "vp":
         np.testing.assert_array_equal(sde.alphas[torch.from_numpy(g[tag + "_aidx"])].numpy(), g[tag + "_alpha"])
     assert tuple(sde.prior_sampling((3, 2, 8, 8)).shape) == (3, 2, 8, 8)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError):                   # guidance is built (tests/test_gpu_guidance.py); CPU tensors still have no path
         S.em_predictor(torch.zeros(1), torch.zeros(1), None, sde, cl_g=object(), given="0", all_mods="01")
 
 
@@ -126,6 +126,65 @@ def test_cpu_baseline_port_matches_reference(golden):
     ts = float(s["vp_0.1_5.0_100_ts"][50])
     xn, xm = TP.vp_em_step(torch.from_numpy(s["x"]), torch.ones(4) * ts, torch.from_numpy(s["score"]), torch.from_numpy(s["noise"]), 0.1, 5.0, 100)
     assert_close(xn.numpy(), s["vp_0.1_5.0_100_em50_x"], 1e-6, 1e-6, "torch port em step")
+
+
+def test_sde_object_api_prior_logp_discretize_reverse(golden):
+    """the parts of the SDE objects no script calls but the drop-in surface carries, against the real classes
+    (sde_helper2.py:236-326, 364-381, 415-421, 457-473): prior_logp, discretize, reverse().sde / .discretize."""
+    g = golden("sde_api.npz")
+    x, sc, t = torch.from_numpy(g["x"]), torch.from_numpy(g["score"]), torch.from_numpy(g["t"])
+    for tag, sde in (("vp", S.VPSDE(0.1, 20.0, 1000)), ("subvp", S.subVPSDE(0.1, 20.0, 1000)), ("ve", S.VESDE(0.01, 50.0, 1000))):
+        assert_close(sde.prior_logp(x).numpy(), g[f"{tag}_logp"], 1e-6, 1e-4, tag + " prior_logp")
+        f, G = sde.discretize(x, t)
+        assert_close(f.numpy(), g[f"{tag}_disc_f"], 1e-6, 1e-7, tag + " discretize f")
+        assert_close(G.numpy(), g[f"{tag}_disc_G"], 1e-6, 1e-7, tag + " discretize G")
+        r = sde.reverse(lambda a, b: sc, False)
+        d, gg = r.sde(x, t)
+        assert_close(d.numpy(), g[f"{tag}_rev_drift"], 1e-6, 1e-5, tag + " reverse drift")
+        assert_close(np.broadcast_to(gg.numpy(), g[f"{tag}_rev_g"].shape), g[f"{tag}_rev_g"], 1e-6, 1e-7, tag + " reverse diffusion")
+        rf, rG = r.discretize(x, t)
+        assert_close(rf.numpy(), g[f"{tag}_rev_disc_f"], 1e-6, 1e-6, tag + " reverse discretize f")
+        assert_close(rG.numpy(), g[f"{tag}_rev_disc_G"], 1e-6, 1e-7, tag + " reverse discretize G")
+        assert r.N == sde.N and r.T == sde.T
+
+
+def test_default_sampler_key_is_fresh_per_call_and_follows_manual_seed():
+    """with seed=None every sampler call draws a new Philox key from torch's default generator (independent noise per
+    call, as the reference's per-call randn_like), and torch.manual_seed reproduces the sequence."""
+    from score_based_multimodal_autoencoder_amd._module import fresh_seed
+    torch.manual_seed(3)
+    a = [fresh_seed(None) for _ in range(3)]
+    torch.manual_seed(3)
+    b = [fresh_seed(None) for _ in range(3)]
+    assert a == b and len(set(a)) == 3
+    assert fresh_seed(17) == 17 and fresh_seed(-1) == 0xFFFFFFFFFFFFFFFF
+
+
+def test_polymnist_scalar_form_surface():
+    """train_poly_unet_cont.py:174: uncond_sampler(sample_shape, model, device, T, eps, beta_0, beta_1, N, ...) exists with the
+    reference's positional order and refuses the CPU (no fallback)."""
+    import inspect
+    from score_based_multimodal_autoencoder_amd import train_poly_unet_cont as P
+    names = list(inspect.signature(P.uncond_sampler).parameters)
+    assert names[:15] == ["sample_shape", "model", "device", "T", "eps", "beta_0", "beta_1", "N", "probability_flow", "pc", "n_steps",
+                          "target_snr", "cl_g", "cl_s", "target"]
+    assert list(inspect.signature(P.corrector).parameters)[:9] == ["x", "t", "score_fn", "beta_0", "beta_1", "N", "T", "n_steps", "target_snr"]
+    with pytest.raises(RuntimeError):
+        P.uncond_sampler((2, 2, 8, 8), lambda x, t: x, "cpu", N=5)
+    with pytest.raises(NotImplementedError):
+        P.uncond_sampler((2, 2, 8, 8), lambda x, t: x, "cuda", T=2, N=5)
+    mean, std = P.marginal_prob(torch.ones(2, 1, 1, 1), torch.tensor([1.0, 0.5]), 0.1, 5.0)
+    rm, rs = S.VPSDE(0.1, 5.0, 10).marginal_prob(torch.ones(2, 1, 1, 1), torch.tensor([1.0, 0.5]))
+    assert torch.equal(mean, rm) and torch.equal(std, rs)
+
+
+def test_guidance_module_state_dict_surface():
+    from score_based_multimodal_autoencoder_amd.lat_sm2_model import ClwithTime2, ClwithTime3
+    assert _shapes(ClwithTime2(n_mod=2, size_z=64, n_class=1)) == {k: tuple(s) for k, s in arch.clg_entries(2, 2, 64, 1)}
+    assert _shapes(ClwithTime3(n_mod=2, size_z=256, n_class=1)) == {k: tuple(s) for k, s in arch.clg_entries(3, 2, 256, 1)}
+    assert [n for n, _ in _lib.specs(_lib.SBM_CLG, [3, 2, 64, 1])] == [k for k, _ in arch.clg_entries(3, 2, 64, 1)]
+    with pytest.raises(NotImplementedError):
+        ClwithTime2(n_mod=3)
 
 
 _WORKER = r"""
