@@ -314,10 +314,11 @@ def main():
             eng.forward_aux(xs, tt, zc, so)
         prof = eng.profile(xs, tt, so, reps=20 if cfg == 2 else 5, sampler_mix=True)      # the launches one SDE step of the timed loop makes
         log("per-kernel profile done")
-        f_seg, f_chain = eng.gemm_flops(sampler_mix=True)
+        f_seg, f_chain, f_row = eng.gemm_flops(sampler_mix=True)
         kern = {}
         for name, label, fl in (("seg_gemm", "seg_gemm<BM,BN> (fp32 MFMA implicit-GEMM conv, one launch per layer)", f_seg),
-                                ("chain_kernel", "chain_kernel (XCD-resident run of the 4x4/2x2/1x1 layers: fp32 MFMA GEMMs + dwconv/attention/GroupNorm glue)", f_chain)):
+                                ("chain_kernel", "chain_kernel (XCD-resident run of the 4x4 and 2x2 layers: fp32 MFMA GEMMs + dwconv/attention/GroupNorm glue)", f_chain),
+                                ("rowrun_kernel", "rowrun_kernel (the 1x1 level: four samples per workgroup, LDS-resident, v_mfma_f32_4x4x1 weight streaming)", f_row)):
             k = prof.get(name, dict(ms=0.0, launches=0))
             if k["launches"] and fl > 0:
                 kern[name] = dict(kernel=label, launches_per_forward=k["launches"], avg_launch_us=1e3 * k["ms"] / k["launches"], ms_per_forward=k["ms"],

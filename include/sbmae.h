@@ -101,9 +101,10 @@ int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, flo
  * per-block condition GEMM -- is tabulated once per run there and not launched per step). */
 int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, int sampler_mix,
                           double* ms_by_kind, int* launches_by_kind, int n_kinds);
-/* Dense-convention GEMM FLOP per forward executed by seg_gemm launches (out4[0]) and by chain_kernel launches (out4[1]);
- * out4[2], out4[3]: the parts of those that belong to the time path (tabulated once per sampler run, not launched per step). */
-int sbm_model_gemm_flops(const sbm_model* m, double* out4);
+/* Dense-convention GEMM FLOP per forward executed by seg_gemm launches (out6[0]) and by chain_kernel launches (out6[1]);
+ * out6[2], out6[3]: the parts of those that belong to the time path (tabulated once per sampler run, not launched per step);
+ * out6[4]: by the row kernel (the one-position level); out6[5]: inside linattn_qkv_kernel (to_qkv). */
+int sbm_model_gemm_flops(const sbm_model* m, double* out6);
 
 /* SDE description == the reference's SDE objects (sde_helper2.py:329-473). kind: 0 VPSDE, 1 subVPSDE, 2 VESDE;
  * (b0,b1) = (beta_min,beta_max) or (sigma_min,sigma_max). */
@@ -219,6 +220,7 @@ int sbm_debug_op_name(const sbm_model* m, int i, char* name, int cap);
 int sbm_debug_chain_sync(sbm_model* m, unsigned* out, int n_words);
 int sbm_debug_chain_ctl(sbm_model* m, unsigned spin_limit, int skip_arrive);   /* barrier poll limit (0 = default); 1 = force a barrier time-out */
 int sbm_debug_chain_stamps(sbm_model* m, int first, int count, unsigned long long* out_host);
+int sbm_debug_row_stamps(sbm_model* m, int first, int count, unsigned long long* out_host, int* kinds, int cap, int* n_out);
 int sbm_debug_gemm_stamps(sbm_model* m, const float* in_dev, float* out_dev, int i, unsigned long long* stamps_host);
 int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps,
                           double* ms_per_op, double* flops_per_op, int n_ops);

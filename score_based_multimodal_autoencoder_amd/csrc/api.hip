@@ -122,6 +122,7 @@ void sbm_model_destroy(sbm_model* m) {
   // forwards run asynchronously on the CALLER's streams: nothing of this model (workspace, weights, the host-mapped abort word the
   // chain kernel may still write) may be released under a kernel in flight
   (void)hipDeviceSynchronize();
+  rowrun_release(&m->plan);
   if (m->own) (void)hipStreamSynchronize(m->own);
   if (m->d_params) (void)hipFree(m->d_params);
   if (m->d_ws) (void)hipFree(m->d_ws);
@@ -197,6 +198,13 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
       if (ge) { std::string msg = std::string(ge) + " (" + m->plan.ops[i].name + ")"; sbm_model_destroy(m); return fail("sbm_model_create: " + msg); }
     }
     if ((e = hipMemcpy(m->d_cold, cold.data(), sizeof(GemmCold) * nops, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(cold args)", e); }
+    // programs of the row kernel (rowrun.hip).  A level too wide for the LDS (activations of four samples) stays in the chain kernel:
+    // same descriptors, same numerics class, decided here once -- never at launch time.
+    if (const char* re = rowrun_prepare(m->dp)) {
+      if (std::string(re).find("do not fit") == std::string::npos) { std::string msg = re; sbm_model_destroy(m); return fail("sbm_model_create: " + msg); }
+      rowrun_release(&m->plan);
+      for (Op& op : m->plan.ops) if (op.row) { op.row = 0; op.chain = 1; }
+    }
     // op table of the XCD-resident chain kernel (chain.hip)
     bool any_chain = false;
     std::vector<ChainOp> cops(nops);
@@ -331,6 +339,9 @@ int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_de
     if (m->plan.ops[i].chain) {                      // like run_plan: consecutive chain ops of the range share one launch
       while (i + n < last && i + n < nops && m->plan.ops[i + n].chain) ++n;
       e = launch_chain(m->dp, i, n, st);
+    } else if (m->plan.ops[i].row) {
+      while (i + n < last && i + n < nops && m->plan.ops[i + n].row) ++n;
+      e = launch_rowrun(m->dp, i, n, st);
     } else {
       e = launch_op(m->dp, i, in_dev, out_dev, st);
     }
@@ -405,6 +416,28 @@ int sbm_debug_chain_stamps(sbm_model* m, int first, int count, unsigned long lon
   return 0;
 }
 
+// run row-kernel ops [first, first + count) in one launch with time stamps armed: out[i] = program op i starts (workgroup 0), out[n] = end;
+// kinds[i] = op kind * 1000 + GEMM passes.  Returns the number of program ops (staging pseudo-ops included) through *n_out.
+int sbm_debug_row_stamps(sbm_model* m, int first, int count, unsigned long long* out_host, int* kinds, int cap, int* n_out) {
+  if (!m || !out_host || !kinds || !n_out || cap <= 0) return fail("sbm_debug_row_stamps: bad arguments");
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 256));
+  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 256));
+  for (int rep = 0; rep < 3; ++rep) {
+    g_row_dbg = d;
+    const char* e = launch_rowrun(m->dp, first, count, m->own);
+    g_row_dbg = nullptr;
+    if (e) { (void)hipFree(d); return fail(e); }
+    HIPCHK(hipStreamSynchronize(m->own));
+  }
+  const int n = rowrun_program_ops(m->dp, first, count, kinds, cap);
+  if (n < 0 || n + 1 > 256) { (void)hipFree(d); return fail("sbm_debug_row_stamps: no such program"); }
+  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (n + 1 < cap ? n + 1 : cap), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  *n_out = n;
+  return 0;
+}
+
 // per-op variant of sbm_model_profile: ms_per_op[i], flops_per_op[i], grid_per_op[i] for i < n_ops
 int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, double* ms_per_op, double* flops_per_op, int n_ops) {
   if (!m || !in_dev || !out_dev || reps <= 0 || !ms_per_op) return fail("sbm_debug_profile_ops: bad arguments");
@@ -466,6 +499,10 @@ int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev,
         if (n > CHAIN_MAX_OPS) n = CHAIN_MAX_OPS;              // one launch per event pair
         e = launch_chain(m->dp, i, n, st);
         bucket.push_back(11);
+      } else if (m->plan.ops[i].row) {
+        while (i + n < nops && m->plan.ops[i + n].row) ++n;
+        e = launch_rowrun(m->dp, i, n, st);
+        bucket.push_back(13);
       } else {
         e = launch_op(m->dp, i, in_dev, out_dev, st);
         bucket.push_back(m->plan.ops[i].kind);
@@ -488,16 +525,17 @@ int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev,
 // Dense-convention GEMM FLOP (2*MAC, zero-padding taps counted) per forward, split by the kernel that executes them:
 // out[0] = seg_gemm launches, out[1] = chain_kernel launches; out[2], out[3] = the parts of out[0], out[1] that belong to the
 // time path (not launched per step inside sbm_sampler_run).
-int sbm_model_gemm_flops(const sbm_model* m, double* out4) {
-  if (!m || !out4) return fail("sbm_model_gemm_flops: bad arguments");
-  double chain = 0.0, chain_t = 0.0, seg_t = m->plan.flops_dense_cond, other = 0.0;
+int sbm_model_gemm_flops(const sbm_model* m, double* out6) {
+  if (!m || !out6) return fail("sbm_model_gemm_flops: bad arguments");
+  double chain = 0.0, chain_t = 0.0, seg_t = m->plan.flops_dense_cond, other = 0.0, row = 0.0;
   for (const Op& op : m->plan.ops) {
     if (op.kind != OP_GEMM) continue;
     if (op.chain) { chain += op.flops_dense; if (op.time_path) chain_t += op.flops_dense; }
+    else if (op.row) row += op.flops_dense;
     else if (op.time_path) seg_t += op.flops_dense;
     else if (op.fuse_next) other += op.flops_dense;           // executed inside linattn_qkv_kernel
   }
-  out4[0] = m->plan.flops_dense_gemm - chain - other; out4[1] = chain; out4[2] = seg_t; out4[3] = chain_t;
+  out6[0] = m->plan.flops_dense_gemm - chain - other - row; out6[1] = chain; out6[2] = seg_t; out6[3] = chain_t; out6[4] = row; out6[5] = other;
   return 0;
 }
 

@@ -108,7 +108,7 @@ struct Ctx {
   int b0, B;             // first sample of the tile being carried, batch size
   float* smem; float2* mr; unsigned* flag;
   unsigned* bar; unsigned gen; ChainSync* sync;
-  unsigned spin_limit; unsigned* abort_host; bool skip_arrive;
+  unsigned spin_limit; unsigned* abort_host; bool skip_arrive; bool no_prefetch;
   unsigned long long* tr;   // diagnostics: per-op trace slots of the stamping workgroup (null otherwise)
 };
 #define TR(i) do { if (c.tr && c.tid == 0) c.tr[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -157,7 +157,7 @@ static DEVINL bool cluster_barrier(Ctx& c, const ChainOp* next) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (c.tid == 0 && !c.skip_arrive) ctr_add(c.bar, 1u);
-  const unsigned sink = next ? prefetch_next(*next, c) : 0u;
+  const unsigned sink = (next && !c.no_prefetch) ? prefetch_next(*next, c) : 0u;
   if (c.tid == 0) {
     unsigned spins = 0, ok = 1;
     while (ctr_load(c.bar) < c.gen) {
@@ -227,9 +227,12 @@ static DEVINL void load_fragm(FragM& f, const GemmHot& g, const int4 d, int b0, 
   }
 }
 // younger: the next chunk's eight loads were issued after this chunk's and may stay in flight
-static DEVINL void wait_fragm(FragM& f, bool younger) {
+// younger: how many chunks issued after this one (8 loads each) may stay in flight
+static DEVINL void wait_fragm(FragM& f, int younger) {
   if constexpr (NA16 == 4) {
-    if (younger) asm volatile("s_waitcnt vmcnt(8)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+    if (younger >= 3) asm volatile("s_waitcnt vmcnt(24)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+    else if (younger == 2) asm volatile("s_waitcnt vmcnt(16)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(8)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
     else asm volatile("s_waitcnt vmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
   } else {                                                    // 16-row tiles: six loads per chunk
     if (younger) asm volatile("s_waitcnt vmcnt(6)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3])::"memory");
@@ -400,8 +403,9 @@ static DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    // this wave's chunks of [lo, hi): lo + wave, lo + wave + NW, ...; PF of them in flight
-    constexpr int PF = 2;
+    // this wave's chunks of [lo, hi): lo + wave, lo + wave + NW, ...; PF of them in flight (4 waves per workgroup have 512 registers
+    // each: four chunks deep; 8 waves: two)
+    constexpr int PF = (NT == 256 && NA16 == 4) ? 4 : 2;
     auto run = [&](int lo, int hi) {
       const int first = lo + c.wave;
       if (first >= hi) return;
@@ -414,7 +418,7 @@ static DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
         for (int sI = 0; sI < PF; ++sI) {
           if (k + sI < nk) {
             float av[16];
-            wait_fragm(f[sI], k + sI + 1 < nk);
+            { const int rem = nk - 1 - (k + sI); wait_fragm(f[sI], rem < PF - 1 ? rem : PF - 1); }
             stage_fragm(f[sI], atile, c.lane, av);
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], f[sI].w[j >> 2][j & 3], acc, 0, 0, 0);
@@ -755,7 +759,7 @@ static DEVINL void chain_gn_res(const GnResArgs& gsrc, Ctx& c) {
 }  // namespace
 
 template <int NT, int GROUPS>
-__global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainOp* __restrict__ ops, int count, ChainSync* sync, int B, unsigned long long* dbg, const ChainCtl ctl) {
+__global__ __launch_bounds__(NT, (NT == 512 || GROUPS == 2) ? 2 : 1) void chain_kernel(const ChainOp* __restrict__ ops, int count, ChainSync* sync, int B, unsigned long long* dbg, const ChainCtl ctl) {
   using K = ChainImpl<NT, GROUPS>;
   using Ctx = typename K::Ctx;
   __shared__ __attribute__((aligned(16))) float smem[K::SMEM_F];
@@ -808,7 +812,8 @@ __global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainOp* __restrict_
   bool alive = info[4] != 0;
   const unsigned cl = xcc * GROUPS + info[5];                  // cluster id
   c.bar = &sync->bar[cl * 16];
-  c.skip_arrive = ctl.debug_skip && ci == 0 && c.slot == 0;     // test knob: this workgroup never announces itself at a barrier
+  c.skip_arrive = (ctl.debug_skip & 1u) && ci == 0 && c.slot == 0;     // test knob: this workgroup never announces itself at a barrier
+  c.no_prefetch = (ctl.debug_skip & 2u) != 0;                          // experiment knob: no weight touches during the barriers
   const int tiles = (B + K::TROWS - 1) / K::TROWS;
   const bool stamp = dbg && ci == 0 && c.slot == 0 && c.tid == 0;
   if (stamp) dbg[0] = __builtin_amdgcn_s_memtime();
@@ -868,11 +873,14 @@ const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st
     if ((op.kind == OP_LINATTN || op.kind == OP_ATTN) && op.at.dh != 32) return "attention: dim_head must be 32";
     if (op.kind == OP_ATTN && op.at.qkv.H * op.at.qkv.W > 16) return "chain kernel: softmax attention over more than 16 positions";
   }
+  static const bool no_pf = std::getenv("SBM_CHAIN_NO_PREFETCH") != nullptr;
+  ChainCtl ctl = dp.chain_ctl;
+  if (no_pf) ctl.debug_skip |= 2u;
   for (int done = 0; done < count; done += CHAIN_MAX_OPS) {
     const ChainOp* ops = dp.chain_ops + first + done;
     const int n = count - done < CHAIN_MAX_OPS ? count - done : CHAIN_MAX_OPS;
-    if (g_prof_start) hipExtLaunchKernelGGL((chain_kernel<512, 1>), dim3(dp.chain_grid), dim3(512), 0, st, g_prof_start, g_prof_stop, 0, ops, n, dp.chain_sync, plan.B, g_chain_dbg, dp.chain_ctl);
-    else hipLaunchKernelGGL((chain_kernel<512, 1>), dim3(dp.chain_grid), dim3(512), 0, st, ops, n, dp.chain_sync, plan.B, g_chain_dbg, dp.chain_ctl);
+    if (g_prof_start) hipExtLaunchKernelGGL((chain_kernel<512, 1>), dim3(dp.chain_grid), dim3(512), 0, st, g_prof_start, g_prof_stop, 0, ops, n, dp.chain_sync, plan.B, g_chain_dbg, ctl);
+    else hipLaunchKernelGGL((chain_kernel<512, 1>), dim3(dp.chain_grid), dim3(512), 0, st, ops, n, dp.chain_sync, plan.B, g_chain_dbg, ctl);
   }
   return nullptr;
 }

@@ -80,6 +80,31 @@ struct ChainCtl {           // launch-invariant controls, passed by value
   unsigned debug_skip;      // test knob: one workgroup never arrives at its barriers, so that they time out
 };
 
+// ---- row kernel (rowrun.hip): the one-position level, four samples per workgroup, activations in LDS ----
+constexpr int ROW_R = 4;            // samples per workgroup (= the rows of v_mfma_f32_4x4x1_16b_f32)
+constexpr int ROW_STAGE = 100;      // pseudo-op: copy a workspace tensor (and its GroupNorm partial sums) into LDS
+struct RowEnt { int w_off; int a_lds; int nch; int src2; };   // weight float offset, LDS offset of the source pixel slab, K chunks of 8, source 2?
+struct RowOpD {
+  int kind;                          // OP_GEMM, OP_DWCONV7, OP_GN_RES, ROW_STAGE
+  int P_out, Npad, nstore, act, ldo, nblk;
+  int gn_stat, stat_out;             // LDS statistics slots: consumed (GroupNorm of source 1 / of u), produced; -1 none
+  int in_lds, out_lds, out_pix, res_lds, res_pix;
+  int ent_first[4], ent_cnt[4], res_p2[4];
+  float gn_inv;
+  const float* Wt; const float* Wt2; const RowEnt* ent;
+  const float* bias; const float* gn_s; const float* gn_b1;
+  float* out_g; float2* stat_g;
+  DwArgs dw; GnResArgs gr;
+  const float* st_src; const float2* st_part; int st_ld, st_C, st_P, st_lds, st_pix, st_stat, st_nparts;
+  int pf_next; int pf_lines[7]; const float* pf_ptr[7];   // L2 prefetch (rowrun.hip, prefetch role): this op's weight spans and epilogue vectors (128-byte lines)
+};
+struct DevPlan;
+const char* launch_rowrun(const DevPlan& dp, int first, int count, hipStream_t st);
+void rowrun_release(const Plan* plan);
+const char* rowrun_prepare(const DevPlan& dp);
+extern unsigned long long* g_row_dbg;
+int rowrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap);   // diagnostics: kind * 1000 + passes per program op
+
 // A plan resolved against its device arenas.
 struct DevPlan {
   const Plan* plan = nullptr;

@@ -571,6 +571,73 @@ __global__ __launch_bounds__(256) void dwconv7_w8_kernel(const DwArgs d) {
   }
 }
 
+// 8 x 8 variant with the sample's whole image in LDS: one workgroup per sample stages the 64 pixels x C channels (coalesced 16-byte
+// loads, one L2 round trip) and the 49 x C weights, then a thread owns (channel quad, output row) and walks the window rows: per
+// row 8 pixel + 7 weight LDS reads feed 8 outputs x 7 taps.  ~15 LDS reads per 56 tap-FMAs instead of ~14 global loads per 28.
+// Taps accumulate in (ky, kx) order and the statistics in channel order, as in dwconv7_kernel.
+__global__ __launch_bounds__(256) void dwconv7_t8_kernel(const DwArgs d) {
+  extern __shared__ __attribute__((aligned(16))) float4 dw_sm[];
+  const int C4 = d.C >> 2, b = blockIdx.x, tid = threadIdx.x;
+  float4* tile = dw_sm;                 // [64][C4]
+  float4* wt = dw_sm + 64 * C4;         // [49][C4]
+  for (int idx = tid; idx < 64 * C4; idx += 256) {
+    const int p = idx / C4, c4 = idx - p * C4;
+    tile[idx] = *reinterpret_cast<const float4*>(d.in + ((long long)p * d.B + b) * d.ldi + 4 * c4);
+  }
+  for (int idx = tid; idx < 49 * C4; idx += 256) wt[idx] = *reinterpret_cast<const float4*>(d.w + 4 * idx);
+  __syncthreads();
+  const int c4 = tid % C4, oy = tid / C4;
+  const bool active = tid < 8 * C4;
+  float4 acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active) {
+    const int ky0 = max(0, 3 - oy), ky1 = min(7, 8 + 3 - oy);
+    for (int ky = ky0; ky < ky1; ++ky) {
+      const int iy = oy - 3 + ky;
+      float4 x[8], w[7];
+#pragma unroll
+      for (int ix = 0; ix < 8; ++ix) x[ix] = tile[(iy * 8 + ix) * C4 + c4];
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) w[kx] = wt[(ky * 7 + kx) * C4 + c4];
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+#pragma unroll
+        for (int kx = 0; kx < 7; ++kx) {
+          const int ix = o - 3 + kx;
+          if (ix >= 0 && ix < 8) {
+            acc[o].x = fmaf(x[ix].x, w[kx].x, acc[o].x); acc[o].y = fmaf(x[ix].y, w[kx].y, acc[o].y);
+            acc[o].z = fmaf(x[ix].z, w[kx].z, acc[o].z); acc[o].w = fmaf(x[ix].w, w[kx].w, acc[o].w);
+          }
+        }
+    }
+    const float4 bi = *reinterpret_cast<const float4*>(d.bias + 4 * c4);
+    float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d.cond) cv = *reinterpret_cast<const float4*>(dw_cond_row(d, b) + 4 * c4);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) {
+      acc[o].x += bi.x; acc[o].y += bi.y; acc[o].z += bi.z; acc[o].w += bi.w;
+      if (d.cond) { acc[o].x += cv.x; acc[o].y += cv.y; acc[o].z += cv.z; acc[o].w += cv.w; }
+      *reinterpret_cast<float4*>(d.out + ((long long)(oy * 8 + o) * d.B + b) * d.ldo + 4 * c4) = acc[o];
+    }
+  }
+  if (d.stat) {
+    __syncthreads();                                              // the image is dead: its LDS holds the per-thread partials [64][C4]
+    float2* red = reinterpret_cast<float2*>(dw_sm);
+    if (active) {
+#pragma unroll
+      for (int o = 0; o < 8; ++o)
+        red[(oy * 8 + o) * C4 + c4] = make_float2(acc[o].x + acc[o].y + acc[o].z + acc[o].w, acc[o].x * acc[o].x + acc[o].y * acc[o].y + acc[o].z * acc[o].z + acc[o].w * acc[o].w);
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float ss = 0.f, qq = 0.f;
+      for (int i = 0; i < C4; ++i) { ss += red[tid * C4 + i].x; qq += red[tid * C4 + i].y; }
+      d.stat[(long long)tid * d.B + b] = make_float2(ss, qq);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LinearAttention core (unet_model.py:169-175): one wave per (sample, head); lane = head dim d,
 // the two 32-lane halves take alternate pixels.
@@ -1025,7 +1092,7 @@ __global__ void sinus_kernel(const float* t, const float* freq, float* out, int 
 // GroupNorm(G, C) (+ SiLU), materialised (unet_openai normalization()): one workgroup per sample; every thread
 // always touches the same channel quads, hence the same groups, so the group sums reduce in a fixed order.
 // ------------------------------------------------------------------------------------------------
-struct Gn32Args { const float* in; float* out; const float* gamma; const float* beta; int B, P, C, ldi, ldo, groups, silu; };
+struct Gn32Args { const float* in; float* out; const float* gamma; const float* beta; int B, P, C, ldi, ldo, groups, silu, slices; };
 
 __global__ __launch_bounds__(256) void gn32_kernel(const Gn32Args a) {
   __shared__ float2 part[256 * 2];
@@ -1063,12 +1130,16 @@ __global__ __launch_bounds__(256) void gn32_kernel(const Gn32Args a) {
     stat[tid] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
   }
   __syncthreads();
+  // With few samples one workgroup per sample leaves most of the chip idle (B = 64: 64 of 256 CUs, each streaming the sample three
+  // times): blockIdx.y cuts the pixels into `slices`; every slice's workgroup repeats the statistics pass over the whole sample
+  // (L2-resident) and normalises only its own pixels -- same sums in the same order, so the result does not depend on the cut.
+  const int slice = blockIdx.y, stride = rows_per_iter * a.slices;
   for (int k = 0; k < npt; ++k) {
     const int c4 = q0 + k * 256;
     if (c4 >= c4n || !active) continue;
     const float2 st = stat[(c4 * 4) / cg];
     const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c4 * 4), be = *reinterpret_cast<const float4*>(a.beta + c4 * 4);
-    for (int p = prow; p < a.P; p += rows_per_iter) {
+    for (int p = prow + slice * rows_per_iter; p < a.P; p += stride) {
       float4 v = *reinterpret_cast<const float4*>(a.in + ((long long)p * a.B + b) * a.ldi + c4 * 4);
       v.x = ((v.x - st.x) * st.y) * ga.x + be.x; v.y = ((v.y - st.x) * st.y) * ga.y + be.y;
       v.z = ((v.z - st.x) * st.y) * ga.z + be.z; v.w = ((v.w - st.x) * st.y) * ga.w + be.w;
@@ -1263,11 +1334,16 @@ static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, 
 const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ext_out, hipStream_t st) {
   const Plan& plan = *dp.plan; const Op& op = plan.ops[idx]; const float* prm = dp.prm; float* ws = dp.ws;
   if (op.chain) return launch_chain(dp, idx, 1, st);
+  if (op.row) return launch_rowrun(dp, idx, 1, st);
   switch (op.kind) {
     case OP_GEMM: return launch_gemm(op.g, dp.hot[idx], ext_in, ext_out, st);
     case OP_DWCONV7: {
       const DwOp& o = op.dw; const DwArgs d = make_dw_args(plan, o, prm, ws, dp.ctl);
-      if (o.in.W == 8 && o.in.C / 4 <= 64 && o.in.C / 4 >= 4 && (256 % (o.in.C / 4)) == 0 && !getenv("SBM_NO_DW8")) {
+      if (o.in.W == 8 && o.in.H == 8 && o.in.C / 4 <= 32 && !getenv("SBM_NO_DWT8")) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_t8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
+        SBM_KLAUNCH(dwconv7_t8_kernel, dim3(o.B), dim3(256), (size_t)(64 + 49) * (o.in.C / 4) * 16, st, d);
+      } else if (o.in.W == 8 && o.in.C / 4 <= 64 && o.in.C / 4 >= 4 && (256 % (o.in.C / 4)) == 0 && !getenv("SBM_NO_DW8")) {
         SBM_KLAUNCH(dwconv7_w8_kernel, dim3(o.in.H * 2, ceil_div(o.B, d.spb)), dim3(256), 0, st, d);
       } else {
         dim3 grid(o.in.H * o.in.W, ceil_div(o.B, d.spb));
@@ -1315,8 +1391,13 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       a.in = ws + o.in.off; a.out = ws + o.out.off; a.gamma = prm + o.gamma_off; a.beta = prm + o.beta_off;
       a.B = o.B; a.P = o.in.H * o.in.W; a.C = o.in.C; a.ldi = o.in.ld; a.ldo = o.out.ld; a.groups = o.groups; a.silu = o.silu;
       if (o.in.C % o.groups || o.in.C > 2048 || o.groups > 64) return "gn32: C must be a multiple of the group count and <= 2048";
+      {
+        const int c4n = a.C / 4, rpi = c4n >= 256 ? 1 : 256 / c4n, sweeps = ceil_div(a.P, rpi);     // pixel sweeps of one workgroup
+        int sl = ceil_div(512, o.B);                                                                  // aim at >= 512 workgroups
+        a.slices = sl < 1 ? 1 : (sl > sweeps ? sweeps : (sl > 16 ? 16 : sl));
+      }
       if (o.in.C % (4 * o.groups)) SBM_KLAUNCH(gn32_small_kernel, dim3(ceil_div(o.B * o.groups, 256)), dim3(256), 0, st, a);
-      else SBM_KLAUNCH(gn32_kernel, dim3(o.B), dim3(256), 0, st, a);
+      else SBM_KLAUNCH(gn32_kernel, dim3(o.B, a.slices), dim3(256), 0, st, a);
     } break;
     case OP_ATTN_QKV: {
       const AttnQkvOp& o = op.aq; AttnQkvArgs a{};
@@ -1371,6 +1452,9 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
     if (plan.ops[i].chain) {                        // a maximal run of chain ops is ONE launch
       while (i + n < (int)plan.ops.size() && plan.ops[i + n].chain && !skipped(i + n)) ++n;
       e = launch_chain(dp, i, n, st);
+    } else if (plan.ops[i].row) {                   // ... and so is a run of row-kernel ops (the one-position level)
+      while (i + n < (int)plan.ops.size() && plan.ops[i + n].row && !skipped(i + n)) ++n;
+      e = launch_rowrun(dp, i, n, st);
     } else {
       e = launch_op(dp, i, ext_in, ext_out, st);
     }

@@ -291,6 +291,15 @@ class Builder {
   void free_act(const View& v) { ws_free(v.off); }
   int64_t new_stats(int nparts, bool pin = false) { return ws_alloc((int64_t)nparts * B * 2, pin); }
   int chain_pix = 0;        // ops with P <= chain_pix are marked for the chain kernel
+  int row_pix = 0;          // ... and of those, ops with P <= row_pix for the row kernel (rowrun.hip)
+  // [tap][Npad][Kp] (k contiguous) -> [tap][Kp][Npad] (n contiguous): the row kernel streams weights with the output column on the lane
+  int64_t add_transposed(const std::vector<float>& w, int ntap, int Npad, int Kp) {
+    std::vector<float> t(w.size());
+    for (int tp = 0; tp < ntap; ++tp)
+      for (int n = 0; n < Npad; ++n)
+        for (int k = 0; k < Kp; ++k) t[((size_t)tp * Kp + k) * Npad + n] = w[((size_t)tp * Npad + n) * Kp + k];
+    return add_params(t);
+  }
 
   // ---- tile choice ----
   // kchunks: K depth in 32-wide chunks; a very short K loop makes the launch prologue/epilogue-bound, where more, smaller
@@ -367,7 +376,14 @@ class Builder {
     const int nstore = s.out_nchw ? s.cout : pad8(s.cout);
     g.Npad = round_up(nstore, 32);
     g.Kp = round_up(s.a.C, 32);
-    g.w_off = add_params(pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, g.Kp, g.Npad, s.transposed, s.out_scale, s.gn ? s.gamma : nullptr));
+    const int P_in_px = s.a.H * s.a.W, P_out_px = s.Hout * s.Wout;
+    const bool row_op = row_pix > 0 && chain_pix > 0 && !s.out_nchw && s.up == 1 && s.up2 == 1 &&
+                        ((P_out_px <= row_pix && P_in_px <= 4 * row_pix) || (P_in_px <= row_pix && P_out_px <= 4 * row_pix)) && P_in_px <= 4 && P_out_px <= 4;
+    {
+      std::vector<float> packed = pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, g.Kp, g.Npad, s.transposed, s.out_scale, s.gn ? s.gamma : nullptr);
+      if (row_op) g.wt_off = add_transposed(packed, s.kh * s.kw, g.Npad, g.Kp);
+      g.w_off = add_params(packed);
+    }
     std::vector<double> bias(g.Npad, 0.0);
     bool any_bias = false;
     if (s.bias) { for (int n = 0; n < s.cout; ++n) bias[n] += (s.out_scale ? (*s.out_scale)[n] : 1.0) * s.bias[n]; any_bias = true; }
@@ -402,7 +418,9 @@ class Builder {
     if (s.has2) {
       g.has2 = 1; g.a2 = s.a2; g.up2 = s.up2;
       g.Kp2 = round_up(s.a2.C, 32);
-      g.w2_off = add_params(pack_conv(s.w2, s.cout, s.cin2, 1, 1, s.cm2, g.Kp2, g.Npad, false, nullptr));
+      std::vector<float> packed2 = pack_conv(s.w2, s.cout, s.cin2, 1, 1, s.cm2, g.Kp2, g.Npad, false, nullptr);
+      if (row_op) g.wt2_off = add_transposed(packed2, 1, g.Npad, g.Kp2);
+      g.w2_off = add_params(packed2);
       if (s.bias2) { for (int n = 0; n < s.cout; ++n) bias[n] += s.bias2[n]; any_bias = true; }
     }
     if (any_bias) { std::vector<float> bf(bias.begin(), bias.end()); g.bias_off = add_params(bf); }
@@ -411,6 +429,7 @@ class Builder {
     const int P = s.Hout * s.Wout;
     choose_tile(B, P, nstore, &g.BM, &g.BN, s.kh * s.kw * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0));
     if (chain_pix > 0 && P <= chain_pix && !s.out_nchw) { op.chain = 1; g.BM = 32; g.BN = 32; }
+    if (row_op) { op.row = 1; op.chain = 0; g.BM = 32; g.BN = 32; }
     ConvResult res;
     if (s.out_nchw) {
       g.out_nchw = 1; g.crop_y = s.crop_y; g.crop_x = s.crop_x; g.Hn = s.Hn; g.Wn = s.Wn;
@@ -422,7 +441,7 @@ class Builder {
     if (s.want_stats) {
       const int ntiles = ceil_div(nstore, g.BN);
       res.stat_nparts = P * ntiles;
-      res.stat_off = g.stat_off = new_stats(res.stat_nparts, op.chain != 0);
+      res.stat_off = g.stat_off = new_stats(res.stat_nparts, op.chain != 0 || op.row != 0);
     }
     // flop accounting
     double taps_valid = 0;
@@ -456,6 +475,7 @@ BlockIO emit_convnext(Builder& b, const std::string& pre, const View& x, const C
   {
     Op& op = b.push(OP_DWCONV7, pre + "ds_conv");
     if (b.chain_pix > 0 && P <= b.chain_pix) op.chain = 1;
+    if (b.chain_pix > 0 && b.row_pix > 0 && P <= b.row_pix) { op.row = 1; op.chain = 0; }
     DwOp& d = op.dw; d.B = b.B; d.in = x; d.out = h0;
     const float* w = b.T(pre + "ds_conv.weight", (int64_t)cin * 49);
     std::vector<float> wp((size_t)49 * x.C, 0.f);
@@ -533,6 +553,7 @@ View emit_attention(Builder& b, const std::string& pre, const View& x, int c, in
       View out = dest ? *dest : b.new_act(H, W, c);
       Op& op = b.push(OP_GN_RES, pre + "fn.fn.to_out.1+residual");
       if (b.chain_pix > 0 && P <= b.chain_pix) op.chain = 1;
+      if (b.chain_pix > 0 && b.row_pix > 0 && P <= b.row_pix) { op.row = 1; op.chain = 0; }
       GnResOp& g = op.gr; g.B = b.B; g.u = ro.out; g.x = x; g.out = out;
       g.part_off = ro.stat_off; g.nparts = ro.stat_nparts; g.inv_count = 1.0f / ((float)c * P);
       g.gamma_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.weight", c), c, nullptr, x.C));
@@ -572,6 +593,7 @@ View emit_attention(Builder& b, const std::string& pre, const View& x, int c, in
     out = dest ? *dest : b.new_act(H, W, c);
     Op& op = b.push(OP_GN_RES, pre + "fn.fn.to_out.1+residual");
     if (b.chain_pix > 0 && P <= b.chain_pix) op.chain = 1;
+    if (b.chain_pix > 0 && b.row_pix > 0 && P <= b.row_pix) { op.row = 1; op.chain = 0; }
     GnResOp& g = op.gr; g.B = b.B; g.u = ro.out; g.x = x; g.out = out;
     g.part_off = ro.stat_off; g.nparts = ro.stat_nparts; g.inv_count = 1.0f / ((float)c * P);
     g.gamma_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.weight", c), c, nullptr, x.C));
@@ -603,11 +625,18 @@ int chain_pix_from_env(int B) {
   return v < 0 ? 0 : (v > 64 ? 64 : v);
 }
 
+int row_pix_from_env() {
+  const char* e = std::getenv("SBM_ROW_PIX");
+  const int v = e ? std::atoi(e) : 1;
+  return v <= 0 ? 0 : 1;              // the row kernel carries the one-position level only
+}
+
 bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Plan* plan) {
   try {
     std::vector<TensorSpec> specs = unet_tensor_specs(cfg);
     Builder b(plan, B, specs, tensors);
     b.chain_pix = chain_pix_from_env(B);
+    b.row_pix = b.chain_pix > 0 ? row_pix_from_env() : 0;
     UnetDims d = unet_dims(cfg);
     const int n = (int)d.in_out.size();
     const int Hp = next_pow2(cfg.H), Wp = next_pow2(cfg.W);       // unet_model.py:276-284
@@ -667,7 +696,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       plan->flops_exec += op.flops;
       b.free_act(e2);   // ops run in stream order: e2 is dead once the GEMM above has executed
       plan->cond_off = cond_off; plan->cond_ld = cond_ld;
-      for (Op& o : plan->ops) if (o.kind != OP_NCHW_TO_PBC) o.time_path = 1;      // everything emitted so far except the input conversion
+      for (Op& o : plan->ops) if (o.kind != OP_NCHW_TO_PBC) { o.time_path = 1; if (o.row) { o.row = 0; o.chain = 1; } }      // everything emitted so far except the input conversion (the time MLP stays in the chain kernel)
     }
     const size_t cond_op_index = plan->ops.size() - 1;
     std::vector<float> cond_w, cond_b;

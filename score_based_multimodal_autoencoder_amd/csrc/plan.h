@@ -91,6 +91,7 @@ struct GemmOp {
   //   hdr [P_out] x {first descriptor, chunk count, source-1 chunk count, residual / source-2 pixel p2}
   //   desc[...]  x {A float offset, W float offset, gamma/beta K offset or -1, flags (bit 0: source 2)}
   int64_t hdr_off = -1, desc_off = -1;
+  int64_t wt_off = -1, wt2_off = -1;   // row-kernel ops only: transposed copies of the weights, [tap][Kp][Npad] / [Kp2][Npad] (n contiguous)
   int Kp = 0, Kp2 = 0;    // K stride of the weight rows of source 1 / 2: a.C / a2.C rounded up to 32, zero
                           // filled, so that the kernel needs no K-tail predicate (gamma/beta are padded alike)
 };
@@ -147,6 +148,7 @@ struct Op {
   int fuse_next = 0;      // 1 (set at model creation): this to_qkv GEMM and the LinearAttention core behind it run as one kernel
   int time_path = 0;      // 1: depends on the time input only (sinusoid, time MLP, per-block condition GEMM): the sampler tabulates it
   int chain = 0;          // 1: runs inside the XCD-resident chain kernel (low-resolution ops; GEMM tile 32x32) -- chain.hip
+  int row = 0;            // 1: runs inside the row kernel (the one-position level, four samples per workgroup, LDS-resident) -- rowrun.hip
   GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf; Gn32Op gn; AttnQkvOp aq;
 };
 
@@ -180,6 +182,9 @@ struct Plan {
 // environment variable SBM_CHAIN_PIX by the Unet plan builder (default 16: the 4x4, 2x2 and 1x1 levels); batches smaller
 // than SBM_CHAIN_MIN_B (default 192) do not use the chain kernel.
 int chain_pix_from_env(int B);
+// Ops of the one-position (1x1) level -- and the strided convolutions that enter / leave it -- run in the row kernel when the chain
+// kernel is in use (SBM_ROW_PIX, default 1; 0 = keep them in the chain kernel).
+int row_pix_from_env();
 
 struct UnetCfg {
   int dim = 64, channels = 3, init_dim = 0, out_dim = 0;
