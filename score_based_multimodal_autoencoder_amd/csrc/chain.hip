@@ -405,7 +405,7 @@ static DEVINL void chain_gemm(const ChainGemm& m, int P, Ctx& c) {
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     // this wave's chunks of [lo, hi): lo + wave, lo + wave + NW, ...; PF of them in flight (4 waves per workgroup have 512 registers
     // each: four chunks deep; 8 waves: two)
-    constexpr int PF = (NT == 256 && NA16 == 4) ? 4 : 2;
+    constexpr int PF = 2;
     auto run = [&](int lo, int hi) {
       const int first = lo + c.wave;
       if (first >= hi) return;
@@ -759,7 +759,7 @@ static DEVINL void chain_gn_res(const GnResArgs& gsrc, Ctx& c) {
 }  // namespace
 
 template <int NT, int GROUPS>
-__global__ __launch_bounds__(NT, (NT == 512 || GROUPS == 2) ? 2 : 1) void chain_kernel(const ChainOp* __restrict__ ops, int count, ChainSync* sync, int B, unsigned long long* dbg, const ChainCtl ctl) {
+__global__ __launch_bounds__(NT, 2) void chain_kernel(const ChainOp* __restrict__ ops, int count, ChainSync* sync, int B, unsigned long long* dbg, const ChainCtl ctl) {
   using K = ChainImpl<NT, GROUPS>;
   using Ctx = typename K::Ctx;
   __shared__ __attribute__((aligned(16))) float smem[K::SMEM_F];
