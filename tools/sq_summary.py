@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc passes over tools/traffic_probe.py into per-kernel averages per launch (JSON on stdout).
 
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT \
-              SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace -d gpurun_out/pmc_sq1 -o t --output-format csv -- python3 tools/traffic_probe.py
+              SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES --kernel-trace -d gpurun_out/pmc_sq1 -o t --output-format csv -- python3 tools/traffic_probe.py --config 2
     rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace -d gpurun_out/pmc_sq2 -o t --output-format csv -- python3 tools/traffic_probe.py
     python3 tools/sq_summary.py gpurun_out/pmc_sq1 gpurun_out/pmc_sq2 > profiles/r01_sq_counters.json
 
@@ -10,7 +10,8 @@ Derived: mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x
 a SIMD's matrix pipe is executing (v_mfma_f32_32x32x2_f32 holds it 64 cycles) -- and the split of the waves' resident time into
 parked (s_waitcnt / barrier), issue-stalled and issuing (SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY over SQ_WAVE_CYCLES).
 """
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, hashlib, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for d in sys.argv[1:]:
@@ -35,4 +36,5 @@ for name, ctrs in sorted(acc.items()):
     if "SQ_LDS_IDX_ACTIVE" in e and e["SQ_LDS_IDX_ACTIVE"] > 0 and "SQ_LDS_BANK_CONFLICT" in e:
         e["lds_bank_conflict_frac"] = round(e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"], 4)
     out[name] = e
-print(json.dumps(out, indent=1))
+from score_based_multimodal_autoencoder_amd import _lib
+print(json.dumps({"lib_hash": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16], "kernels": out}, indent=1))
