@@ -27,6 +27,7 @@ struct GemmHot {
   const GemmCold* cold;
   float* out;                           // PBC view origin, or the external NCHW output
   int B, lda, lda2, Kp, Kp2, Npad, mtiles, ntiles;
+  int split; float* part; unsigned* cnt;   // split-K (GemmOp::split): partial tiles and arrival counters in the workspace
   unsigned long long* dbg;              // diagnostic cycle stamps (null in production)
 };
 

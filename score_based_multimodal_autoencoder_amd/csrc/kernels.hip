@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
   constexpr int RING_F = NST * STAGE_F + GN_SCRATCH;
   constexpr int LDS_F = RING_F > 4 * 32 * EP_LD + 4 * BM ? RING_F : 4 * 32 * EP_LD + 4 * BM;
   __shared__ __attribute__((aligned(1024))) float lds[LDS_F];
+  __shared__ int s_last;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -144,6 +145,9 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
   unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_wait = 0, st_comp = 0, st_a = 0, st_b = 0;
   if (g.dbg) st_t0 = __builtin_amdgcn_s_memtime();
   int bid = blockIdx.x;
+  int ks = 0;
+  if (g.split > 1) { ks = bid % g.split; bid /= g.split; }     // the splits of a tile are neighbours in launch order
+  const int tile_id = bid;
   const int nt = bid % g.ntiles; bid /= g.ntiles;
   const int mt = bid % g.mtiles; const int p = bid / g.mtiles;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -152,6 +156,8 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
   const int4 hd = scalar_load16(g.hdr + p);                        // {first descriptor, chunk count, source-1 chunks, p2}
   const int4* __restrict__ dsc = g.desc + hd.x;
   const int total = hd.y;
+  int c0 = 0, c1 = total;                             // this workgroup's chunk range (split-K: an even share of the pixel's list)
+  if (g.split > 1) { c0 = total * ks / g.split; c1 = total * (ks + 1) / g.split; }
 
   // ---- per-lane DMA source row offsets (loop invariant).  Lane l of instruction q = wave + 4j writes LDS row
   //      r = 8q + (l >> 3), physical slot l & 7, and fetches logical slot ls = (l & 7) ^ ((r >> 1) & 7), which
@@ -168,8 +174,8 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
 
   // The DMA of one chunk is issued in IA pieces so that the pieces can be spread between the MFMA groups of the
   // chunk being computed.  Piece 0 fetches the chunk's descriptor (scalar load) and resolves the bases.
-  int is_c = 0, is_stage = 0;
-  int4 is_next = scalar_load16(dsc);                 // descriptor of the next chunk to issue, loaded one chunk ahead
+  int is_c = c0, is_stage = 0;
+  int4 is_next = scalar_load16(dsc + c0);                 // descriptor of the next chunk to issue, loaded one chunk ahead
   const float* is_a = g.A; const float* is_w = g.W;
   bool is_src2 = false;
   float* is_sbase = lds;
@@ -207,8 +213,8 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
   }
 
   // ---- prefill the ring ----
-  int issued = 0;
-  for (; issued < total && issued < NST - 1; ++issued) {
+  int issued = c0;
+  for (; issued < c1 && issued < c0 + NST - 1; ++issued) {
 #pragma unroll
     for (int j = 0; j < IA; ++j) issue_piece(j);
   }
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
       if (issued - (i + 1) >= NST - 2) wait_vmcnt<(NST - 2) * IA>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();            // chunk i landed for every wave; everyone is done with chunk i-1
       if (g.dbg) { st_b = __builtin_amdgcn_s_memtime(); st_wait += st_b - st_a; }
-      const bool do_issue = issued < total;
+      const bool do_issue = issued < c1;
       if (do_issue) ++issued;
       const unsigned sb = lds_base + (unsigned)(cstage * STAGE_F * 4);
       cstage = cstage + 1 == NST ? 0 : cstage + 1;
@@ -337,19 +343,63 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
     }
   };
   if constexpr (GN) {
-    run_chunks(0, hd.z);
+    run_chunks(c0, min(c1, hd.z));
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
       for (int b = 0; b < WN; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] *= rrow[a][r];
-    run_chunks(hd.z, total);
+    run_chunks(max(c0, hd.z), c1);
   } else {
-    run_chunks(0, total);
+    run_chunks(c0, c1);
   }
   if (g.dbg) st_t2 = __builtin_amdgcn_s_memtime();
   __syncthreads();      // all DMA retired (last wait was vmcnt(0)); LDS is reused by the epilogue
+
+  // ---- split-K: park the partial tile in the workspace; the LAST workgroup of the tile to arrive sums all partials in split
+  //      order (so the result does not depend on arrival order) and goes on to the epilogue.  The splits of a tile sit on
+  //      different XCDs, whose L2s are not coherent with each other: partials are written and read with DEVICE-scope accesses
+  //      (sc1: write-through / read-through at the L2, like the arrival counter) -- device-scope FENCES would write back and
+  //      invalidate the whole L2 under the other workgroups' operand streams (measured: +80 us per launch). ----
+  if (g.split > 1) {
+    constexpr int TILE_F = WM * WN * 16 * 256;
+    float* pt = g.part + (long long)tile_id * g.split * TILE_F;
+    float* mine = pt + (long long)ks * TILE_F;
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int b = 0; b < WN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          __hip_atomic_store(mine + ((a * WN + b) * 16 + r) * 256 + tid, acc[a][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wait_vmcnt<0>();                                   // the write-throughs are acknowledged
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(g.cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == (unsigned)(g.split - 1);
+      if (last) __hip_atomic_store(g.cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // clean for the next launch
+      s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+      for (int b = 0; b < WN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    for (int s2 = 0; s2 < g.split; ++s2) {
+      const float* src = pt + (long long)s2 * TILE_F;
+#pragma unroll
+      for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[a][b][r] += __hip_atomic_load(src + ((a * WN + b) * 16 + r) * 256 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 
   // ---- epilogue: out = act(acc + bias + r) and per-row partial (sum, sumsq).  Each wave transposes its 32-row
   //      tile through LDS; then 8*WN consecutive lanes own one row (each lane 4 consecutive columns), so every global
@@ -1266,7 +1316,7 @@ const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, 
   if ((long long)o.B * (o.a.ld > o.a2.ld ? o.a.ld : o.a2.ld) >= (1LL << 30) || (long long)o.Npad * (o.Kp > o.Kp2 ? o.Kp : o.Kp2) >= (1LL << 30))
     return "seg_gemm: operand plane too large for 32-bit lane offsets";
   if (o.hdr_off < 0 || o.desc_off < 0 || plan.ident_off < 0) return "seg_gemm: chunk tables missing";
-  if (!((o.BM == 64 && o.BN == 64) || (o.BM == 128 && o.BN == 64) || (o.BM == 128 && o.BN == 128) || (o.BM == 32 && o.BN == 32))) return "seg_gemm: unsupported tile";
+  if (!((o.BM == 64 && o.BN == 64) || (o.BM == 64 && o.BN == 128) || (o.BM == 128 && o.BN == 64) || (o.BM == 128 && o.BN == 128) || (o.BM == 32 && o.BN == 32))) return "seg_gemm: unsupported tile";
   GemmHot h{};
   h.A = o.a_ext ? nullptr : ws + o.a.off;            // external input patched at launch
   h.A2 = o.has2 ? ws + o.a2.off : nullptr;
@@ -1277,6 +1327,11 @@ const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, 
   h.B = o.B; h.lda = o.a.ld; h.lda2 = o.a2.ld; h.Kp = o.Kp; h.Kp2 = o.Kp2; h.Npad = o.Npad;
   const int nstore = o.out_nchw ? o.N : o.out.C;
   h.mtiles = ceil_div(o.B, o.BM); h.ntiles = ceil_div(nstore, o.BN);
+  h.split = o.split > 1 ? o.split : 1;
+  if (h.split > 1) {
+    if (plan.splitk_part_off < 0 || plan.splitk_cnt_off < 0) return "seg_gemm: split-K scratch missing";
+    h.part = ws + plan.splitk_part_off; h.cnt = reinterpret_cast<unsigned*>(ws + plan.splitk_cnt_off);
+  }
   h.dbg = nullptr;
   GemmCold c{};
   c.bias = o.bias_off >= 0 ? prm + o.bias_off : nullptr;
@@ -1317,7 +1372,7 @@ static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, 
   if (o.a_ext) g.A = ext_in + o.a.off;
   if (o.out_nchw) g.out = ext_out;
   g.dbg = g_gemm_dbg;
-  const long long blocks = (long long)o.Hout * o.Wout * g.mtiles * g.ntiles;
+  const long long blocks = (long long)o.Hout * o.Wout * g.mtiles * g.ntiles * g.split;
   if (blocks <= 0 || blocks > 0x7fffffffLL) return "seg_gemm: bad grid";
   dim3 grid((unsigned)blocks), block(256);
   const bool gn = o.gn != 0;
@@ -1325,6 +1380,7 @@ static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, 
   do { if (gn) SBM_KLAUNCH((seg_gemm<BM_, BN_, NST_, true>), grid, block, 0, st, g); \
        else SBM_KLAUNCH((seg_gemm<BM_, BN_, NST_, false>), grid, block, 0, st, g); } while (0)
   if (o.BM == 64 && o.BN == 64) SBM_LAUNCH(64, 64, 4);
+  else if (o.BM == 64 && o.BN == 128) SBM_LAUNCH(64, 128, 3);
   else if (o.BM == 128 && o.BN == 64) SBM_LAUNCH(128, 64, 4);
   else SBM_LAUNCH(128, 128, 3);
 #undef SBM_LAUNCH

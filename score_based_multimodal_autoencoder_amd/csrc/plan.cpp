@@ -305,8 +305,10 @@ class Builder {
   // kchunks: K depth in 32-wide chunks; a very short K loop makes the launch prologue/epilogue-bound, where more, smaller
   // workgroups overlap better than few large ones
   static void choose_tile(int B, int P, int nstore, int* BM, int* BN, int kchunks = 1 << 20) {
-    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    static const bool wide64 = !getenv("SBM_NO_TILE_64x128");
+    const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     for (auto& c : cand) {
+      if (c[0] == 64 && c[1] == 128 && (!wide64 || B > 64)) continue;
       if (kchunks <= 4 && c[0] > 64) continue;
       if (c[1] > 64 && nstore <= 64) continue;
       if (c[0] > 64 && B <= 64) continue;
@@ -859,7 +861,12 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
   }
 }
 
+static bool splitk_enabled() { static const bool on = !getenv("SBM_NO_SPLITK"); return on; }
+static long splitk_max_tiles() { static const long v = getenv("SBM_SPLITK_TILES") ? atol(getenv("SBM_SPLITK_TILES")) : 384; return v; }
+static const int SPLIT_MIN_CHUNKS = 6;
+
 void finalize_gemm_tables(Plan* plan) {
+  int64_t max_part = 0, max_tiles = 0;
   auto add_ints = [&](const std::vector<int>& v) {
     const int64_t off = (int64_t)plan->params.size();
     plan->params.resize(plan->params.size() + v.size());
@@ -907,6 +914,26 @@ void finalize_gemm_tables(Plan* plan) {
     if (desc.empty()) desc.assign(4, 0);
     g.hdr_off = add_ints(hdr);
     g.desc_off = add_ints(desc);
+    // split-K for grids that leave most of the 256 CUs idle (few pixels x few tiles, long K): aim at two workgroups per CU,
+    // keep at least SPLIT_MIN_CHUNKS chunks per split so the DMA ring still fills
+    if (!op.chain && !op.row && !g.out_nchw && splitk_enabled()) {
+      int minc = 1 << 30;
+      for (int p = 0; p < P; ++p) minc = std::min(minc, hdr[4 * p + 1]);
+      const int nstore = g.out.C;
+      const long tiles = (long)P * ceil_div(g.B, g.BM) * ceil_div(nstore, g.BN);
+      if (tiles < splitk_max_tiles()) {
+        int S = (int)std::min<long>(std::min<long>(ceil_div(512, (int)tiles), minc / SPLIT_MIN_CHUNKS), 16);
+        if (S >= 2) {
+          g.split = S;
+          max_part = std::max<int64_t>(max_part, (int64_t)tiles * S * g.BM * g.BN);
+          max_tiles = std::max<int64_t>(max_tiles, tiles);
+        }
+      }
+    }
+  }
+  if (max_tiles > 0) {
+    plan->splitk_part_off = plan->ws_floats; plan->ws_floats += (max_part + 63) / 64 * 64;
+    plan->splitk_cnt_off = plan->ws_floats; plan->ws_floats += (max_tiles + 63) / 64 * 64;
   }
 }
 

@@ -86,6 +86,8 @@ struct GemmOp {
   int crop_y = 0, crop_x = 0, Hn = 0, Wn = 0;  // out_nchw: crop of the padded grid
   int64_t stat_off = -1;  // workspace: float2 [P_out * ntiles][B] partial (sum, sumsq) of the stored rows
   int BM = 64, BN = 64;   // tile configuration (fixes ntiles = ceil(out.C / BN))
+  int split = 1;          // split-K: each output tile's chunk list is dealt to `split` workgroups; the last to arrive sums the partial tiles
+                          // (fixed order) and runs the epilogue.  Chosen in finalize_gemm_tables for grids that cannot fill the chip.
   // Host-built chunk tables (params arena, stored as int32 bit patterns): the kernel walks K in 32-wide chunks and
   // reads one 16-byte descriptor per chunk instead of doing tap geometry on the device.
   //   hdr [P_out] x {first descriptor, chunk count, source-1 chunk count, residual / source-2 pixel p2}
@@ -174,6 +176,7 @@ struct Plan {
   double flops_exec = 0;         // 2*MAC actually issued (padding taps skipped, channel padding included)
   double flops_dense_gemm = 0;   // the part of flops_dense computed by GEMM ops
   double flops_dense_cond = 0;   // ... of which the per-block time-condition GEMM (a time-path op emitted directly)
+  int64_t splitk_part_off = -1, splitk_cnt_off = -1;   // workspace: partial tiles [tile][split][BM*BN] / arrival counters [tile] shared by all split-K ops
   int64_t ident_off = -1;        // params: 32 ones followed by 32 zeros (identity gamma/beta for chunks without GroupNorm)
   std::string error;
 };
