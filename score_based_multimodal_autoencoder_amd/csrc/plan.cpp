@@ -304,7 +304,21 @@ class Builder {
   // ---- tile choice ----
   // kchunks: K depth in 32-wide chunks; a very short K loop makes the launch prologue/epilogue-bound, where more, smaller
   // workgroups overlap better than few large ones
-  static void choose_tile(int B, int P, int nstore, int* BM, int* BN, int kchunks = 1 << 20) {
+  // split-K policy (finalize_gemm_tables applies it): grids under splitk_max_tiles() tiles are split so that about
+  // splitk_target() workgroups run, each keeping at least splitk_min_chunks() K chunks
+  static bool splitk_enabled() { static const bool on = !getenv("SBM_NO_SPLITK"); return on; }
+  static long splitk_max_tiles() { static const long v = getenv("SBM_SPLITK_TILES") ? atol(getenv("SBM_SPLITK_TILES")) : 384; return v; }
+  static long splitk_target() { static const long v = getenv("SBM_SPLITK_TARGET") ? atol(getenv("SBM_SPLITK_TARGET")) : 512; return v; }
+  static int splitk_min_chunks() { static const int v = getenv("SBM_SPLITK_MINCH") ? atoi(getenv("SBM_SPLITK_MINCH")) : 6; return v; }
+  static int splitk_for(long tiles, int min_chunks) {
+    if (!splitk_enabled() || tiles >= splitk_max_tiles()) return 1;
+    const long S = std::min<long>(std::min<long>((splitk_target() + tiles - 1) / tiles, min_chunks / splitk_min_chunks()), 16);
+    return S >= 2 ? (int)S : 1;
+  }
+
+  // kchunks: dense K chunk count; kmin: the SHORTEST chunk list of an output pixel (border pixels of a padded convolution see fewer taps)
+  static void choose_tile(int B, int P, int nstore, int* BM, int* BN, int kchunks = 1 << 20, int kmin = -1) {
+    if (kmin < 0) kmin = kchunks;
     static const bool wide64 = !getenv("SBM_NO_TILE_64x128");
     const int cand[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
     for (auto& c : cand) {
@@ -313,6 +327,13 @@ class Builder {
       if (c[1] > 64 && nstore <= 64) continue;
       if (c[0] > 64 && B <= 64) continue;
       long blocks = (long)P * ceil_div(B, c[0]) * ceil_div(nstore, c[1]);
+      // batch <= 64: the wide tile also wins when split-K can bring the grid back up (same workgroup count, better reuse per workgroup)
+      // (measured per layer on configs 4 and 5: wide + split pays only while every split keeps >= 20 chunks and S <= 8)
+      if (c[0] == 64 && c[1] == 128) {
+        const int S = splitk_for(blocks, kmin);
+        if (S > 1 && (S > 8 || kmin / S < 20)) continue;
+        blocks *= S;
+      }
       if (blocks >= 384) { *BM = c[0]; *BN = c[1]; return; }
     }
     *BM = 64; *BN = 64;
@@ -429,7 +450,15 @@ class Builder {
     if (s.has_res) { g.has_res = 1; g.r = s.r; g.up2 = s.up2; }
     g.act = s.act;
     const int P = s.Hout * s.Wout;
-    choose_tile(B, P, nstore, &g.BM, &g.BN, s.kh * s.kw * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0));
+    int min_taps = s.kh * s.kw;
+    if (!g.a_rows && !g.a_bcast)
+      for (int p = 0; p < P; ++p) {
+        int nv = 0;
+        for (int ky = 0; ky < s.kh; ++ky) for (int kx = 0; kx < s.kw; ++kx)
+          nv += tap_source_pixel(p / s.Wout, p % s.Wout, ky, kx, s.stride, s.pad, s.transposed ? 1 : 0, s.up, s.a.H, s.a.W) >= 0;
+        min_taps = std::min(min_taps, nv);
+      }
+    choose_tile(B, P, nstore, &g.BM, &g.BN, s.kh * s.kw * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0), min_taps * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0));
     if (chain_pix > 0 && P <= chain_pix && !s.out_nchw) { op.chain = 1; g.BM = 32; g.BN = 32; }
     if (row_op) { op.row = 1; op.chain = 0; g.BM = 32; g.BN = 32; }
     ConvResult res;
@@ -861,10 +890,6 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
   }
 }
 
-static bool splitk_enabled() { static const bool on = !getenv("SBM_NO_SPLITK"); return on; }
-static long splitk_max_tiles() { static const long v = getenv("SBM_SPLITK_TILES") ? atol(getenv("SBM_SPLITK_TILES")) : 384; return v; }
-static const int SPLIT_MIN_CHUNKS = 6;
-
 void finalize_gemm_tables(Plan* plan) {
   int64_t max_part = 0, max_tiles = 0;
   auto add_ints = [&](const std::vector<int>& v) {
@@ -916,18 +941,16 @@ void finalize_gemm_tables(Plan* plan) {
     g.desc_off = add_ints(desc);
     // split-K for grids that leave most of the 256 CUs idle (few pixels x few tiles, long K): aim at two workgroups per CU,
     // keep at least SPLIT_MIN_CHUNKS chunks per split so the DMA ring still fills
-    if (!op.chain && !op.row && !g.out_nchw && splitk_enabled()) {
+    if (!op.chain && !op.row && !g.out_nchw) {
       int minc = 1 << 30;
       for (int p = 0; p < P; ++p) minc = std::min(minc, hdr[4 * p + 1]);
-      const int nstore = g.out.C;
-      const long tiles = (long)P * ceil_div(g.B, g.BM) * ceil_div(nstore, g.BN);
-      if (tiles < splitk_max_tiles()) {
-        int S = (int)std::min<long>(std::min<long>(ceil_div(512, (int)tiles), minc / SPLIT_MIN_CHUNKS), 16);
-        if (S >= 2) {
-          g.split = S;
-          max_part = std::max<int64_t>(max_part, (int64_t)tiles * S * g.BM * g.BN);
-          max_tiles = std::max<int64_t>(max_tiles, tiles);
-        }
+      const long tiles = (long)P * ceil_div(g.B, g.BM) * ceil_div(g.out.C, g.BN);
+      const int S = Builder::splitk_for(tiles, minc);
+      if (getenv("SBM_NAME_TILES")) op.name += " [" + std::to_string(g.BM) + "x" + std::to_string(g.BN) + " s" + std::to_string(S) + " k" + std::to_string(minc) + "]";
+      if (S >= 2) {
+        g.split = S;
+        max_part = std::max<int64_t>(max_part, (int64_t)tiles * S * g.BM * g.BN);
+        max_tiles = std::max<int64_t>(max_tiles, tiles);
       }
     }
   }
@@ -1091,6 +1114,7 @@ bool build_unet_oa_plan(const UnetOACfg& cfg, int B, int with_z, const float* co
     // ---- layer emitters ----
     auto gn32 = [&](const std::string& pre, const View& x, int C, bool silu) {
       View y = b.new_act(x.H, x.W, C);
+      if (plan->gn32_part_off < 0) plan->gn32_part_off = b.ws_alloc((int64_t)B * 16 * 64 * 4, true);
       Op& op = b.push(OP_GN32, pre + (silu ? "+silu" : ""));
       op.gn.B = B; op.gn.in = x; op.gn.out = y; op.gn.groups = 32; op.gn.silu = silu ? 1 : 0;
       op.gn.gamma_off = b.add_params(b.pack_vec(b.T(pre + "weight", C), C, nullptr, C));

@@ -177,6 +177,7 @@ struct Plan {
   double flops_dense_gemm = 0;   // the part of flops_dense computed by GEMM ops
   double flops_dense_cond = 0;   // ... of which the per-block time-condition GEMM (a time-path op emitted directly)
   int64_t splitk_part_off = -1, splitk_cnt_off = -1;   // workspace: partial tiles [tile][split][BM*BN] / arrival counters [tile] shared by all split-K ops
+  int64_t gn32_part_off = -1;    // workspace: fp64 (sum, sumsq) [B][16 slices][64 groups] shared by the two-pass GroupNorm(32) launches
   int64_t ident_off = -1;        // params: 32 ones followed by 32 zeros (identity gamma/beta for chunks without GroupNorm)
   std::string error;
 };
