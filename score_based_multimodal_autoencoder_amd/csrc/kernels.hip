@@ -816,7 +816,8 @@ __global__ __launch_bounds__(64) void linattn_lds_kernel(const AttnArgs a) {
 // Each wave accumulates the context over its quarter of the pixels, the four partial contexts are added in wave order, and
 // each wave produces its quarter of the output pixels.
 __global__ __launch_bounds__(256) void linattn_lds4_kernel(const AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) float sq[64 * 32], sk[64 * 32], sv[64 * 32];      // [pixel][d]
+  extern __shared__ __attribute__((aligned(16))) float la_sm[];      // q, k, v of the (sample, head): 3 x [n pixels][32] (launch: 3 * n * 128 bytes)
+  float* sq = la_sm; float* sk = la_sm + a.n * 32; float* sv = la_sm + 2 * a.n * 32;
   __shared__ float pctx[4][32][33];
   __shared__ float kred[8][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, d = lane & 31, half = lane >> 5;
@@ -846,8 +847,8 @@ __global__ __launch_bounds__(256) void linattn_lds4_kernel(const AttnArgs a) {
   for (int i = kg; i < a.n; i += 8) { const float e = expf(sk[i * 32 + kd] - kmax); sk[i * 32 + kd] = e; ps += e; }
   kred[kg][kd] = ps;
   // ---- q: softmax over the channels, per pixel; 4 threads per pixel, 8 channels each; scaled
-  {
-    const int qi = tid >> 2, part = tid & 3;
+  for (int qi = tid >> 2; qi < ((a.n + 63) & ~63); qi += 64) {
+    const int part = tid & 3;
     if (qi < a.n) {
       float* qp = sq + qi * 32 + part * 8;
       float v[8];
@@ -1498,7 +1499,11 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       const AttnOp& o = op.at; const AttnArgs a = make_attn_args(o, ws);
       if (o.dh != 32) return "attention: dim_head must be 32";
       if (op.kind == OP_ATTN && a.n > 64) return "softmax attention: more than 64 positions";
-      if (op.kind == OP_LINATTN && a.n > 16 && a.n <= 64 && (a.ldq & 3) == 0) SBM_KLAUNCH(linattn_lds4_kernel, dim3(o.B * o.heads), dim3(256), 0, st, a);
+      if (op.kind == OP_LINATTN && a.n > 16 && a.n <= 320 && (a.ldq & 3) == 0 && (a.n <= 64 || !getenv("SBM_NO_LINATTN_BIG"))) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_lds4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 320 * 128); attr_set = true; }     // + 18 KB static: within the 160 KB of a CU
+        SBM_KLAUNCH(linattn_lds4_kernel, dim3(o.B * o.heads), dim3(256), (size_t)3 * a.n * 128, st, a);
+      }
       else if (op.kind == OP_LINATTN && a.n <= 64 && (a.ldq & 3) == 0) SBM_KLAUNCH(linattn_lds_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
       else if (op.kind == OP_LINATTN) SBM_KLAUNCH(linattn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
       else SBM_KLAUNCH(attn_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);
