@@ -916,7 +916,8 @@ __global__ __launch_bounds__(256) void linattn_qkv_kernel(const QkvAttnArgs qa) 
   constexpr int QLD = 33;                                         // q rows are padded: the output MFMA reads q[pixel = lane][k] (a column)
   __shared__ __attribute__((aligned(16))) float sq[64 * QLD], sk[64 * 32], sv[64 * 32];     // [pixel][d]
   __shared__ __attribute__((aligned(16))) float ht[64 * 68];                                 // block input tile [pixel][64 + 4]
-  __shared__ float pctx[4][32][33];
+  float (*pctx)[32][33] = reinterpret_cast<float (*)[32][33]>(ht);                            // [4][32][33] partial contexts: the input tile is dead by then
+  static_assert(4 * 32 * 33 <= 64 * 68, "partial contexts must fit the input tile they alias");
   __shared__ float kred[8][32];
   __shared__ double sred[2][4];
   __shared__ float2 s_mr;
