@@ -1309,39 +1309,70 @@ __global__ void gn32_small_kernel(const Gn32Args a) {
 // unet_openai QKVAttention core (unet_openai.py:346-358): one workgroup per (sample, head), T <= 64 tokens.
 struct AttnQkvArgs { const float* qkv; float* out; int B, T, ldq, ldo, heads, chh; float scale; };
 
+// Thread (t = tid >> 2, part = tid & 3) owns 16 of row t's 64 logits, then 16 of every 64 output channels of token t.  q, k (and later v)
+// pass through LDS in 64-channel chunks (coalesced 256-byte token rows); the softmax of a row lives in the registers of its four
+// threads.  Tokens / channels beyond T / chh are staged as zeros and masked, so any T <= 64 and any head width work.
 __global__ __launch_bounds__(256) void attn_qkv_kernel(const AttnQkvArgs a) {
-  __shared__ float w[64 * 64];
-  __shared__ float red[256];
-  const int tid = threadIdx.x;
+  constexpr int LD = 65;
+  __shared__ float w[64 * LD];               // probabilities [t][u]
+  __shared__ float qs[64 * LD], ks[64 * LD];  // one 64-channel chunk of q and of k (then of v): [token][channel]
+  const int tid = threadIdx.x, tt = tid >> 2, part = tid & 3;
   const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
   const float* base = a.qkv + (long long)b * a.ldq + h * 3 * a.chh;
   const long long ts = (long long)a.B * a.ldq;
   const float s2 = a.scale * a.scale;
-  for (int pair = 0; pair < a.T * a.T; ++pair) {
-    const int t = pair / a.T, u = pair - t * a.T;
-    float acc = 0.f;
-    for (int c = tid; c < a.chh; c += 256) acc = fmaf(base[t * ts + c], base[u * ts + a.chh + c], acc);
-    red[tid] = acc;
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-    if (tid == 0) w[pair] = red[0] * s2;
-    __syncthreads();
-  }
-  if (tid < a.T) {
-    float m = -INFINITY;
-    for (int u = 0; u < a.T; ++u) m = fmaxf(m, w[tid * a.T + u]);
-    float z = 0.f;
-    for (int u = 0; u < a.T; ++u) { const float e = expf(w[tid * a.T + u] - m); w[tid * a.T + u] = e; z += e; }
-    const float inv = 1.0f / z;
-    for (int u = 0; u < a.T; ++u) w[tid * a.T + u] *= inv;
-  }
-  __syncthreads();
-  for (int c = tid; c < a.chh; c += 256)
-    for (int t = 0; t < a.T; ++t) {
-      float acc = 0.f;
-      for (int u = 0; u < a.T; ++u) acc = fmaf(w[t * a.T + u], base[u * ts + 2 * a.chh + c], acc);
-      a.out[((long long)t * a.B + b) * a.ldo + h * a.chh + c] = acc;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int c0 = 0; c0 < a.chh; c0 += 64) {
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int t = idx >> 6, c = idx & 63;
+      const bool ok = t < a.T && c0 + c < a.chh;
+      qs[t * LD + c] = ok ? base[t * ts + c0 + c] : 0.f;
+      ks[t * LD + c] = ok ? base[t * ts + a.chh + c0 + c] : 0.f;
     }
+    __syncthreads();
+    for (int c = 0; c < 64; ++c) {
+      const float qv = qs[tt * LD + c];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = fmaf(qv, ks[(part * 16 + j) * LD + c], acc[j]);
+    }
+    __syncthreads();
+  }
+  {
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc[j] = part * 16 + j < a.T ? acc[j] * s2 : -INFINITY; m = fmaxf(m, acc[j]); }
+    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2));
+    float z = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc[j] = expf(acc[j] - m); z += acc[j]; }
+    z += __shfl_xor(z, 1); z += __shfl_xor(z, 2);
+    const float inv = 1.0f / z;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[tt * LD + part * 16 + j] = acc[j] * inv;
+  }
+  for (int c0 = 0; c0 < a.chh; c0 += 64) {
+    __syncthreads();                           // w complete / previous chunk of v consumed
+    for (int idx = tid; idx < 64 * 64; idx += 256) {
+      const int u = idx >> 6, c = idx & 63;
+      ks[u * LD + c] = (u < a.T && c0 + c < a.chh) ? base[u * ts + 2 * a.chh + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    float o[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = 0.f;
+    for (int u = 0; u < 64; ++u) {
+      const float p = w[tt * LD + u];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[j] = fmaf(p, ks[u * LD + part * 16 + j], o[j]);
+    }
+    if (tt < a.T) {
+      float* dst = a.out + ((long long)tt * a.B + b) * a.ldo + h * a.chh + c0 + part * 16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) if (c0 + part * 16 + j < a.chh) dst[j] = o[j];
+    }
+  }
 }
 
 // rowpack: element (y, x, c) goes to row y, channel x*Cv + c of a [Ho][B][ld] tensor (init_conv's row-packed input)

@@ -21,12 +21,17 @@ ap.add_argument("--channels", type=int, default=5)
 ap.add_argument("--hw", type=int, default=8)
 ap.add_argument("--mults", type=str, default="1,2,2,2")
 ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4, 5), help="score net of a bench.py workload (overrides the shape flags)")
+ap.add_argument("--config", type=int, default=0, choices=(0, 2, 4, 5, 6), help="score net of a bench.py workload (overrides the shape flags); 6 = the DiffuseVAE refiner UNetModel(6->3) at 128x128 (eval_lat_celeba_hq_all.py:448), batch from --batch")
 a = ap.parse_args()
 
 if a.config == 4:
     a.batch, a.dim, a.channels, a.hw, a.mults = 64, 256, 3, 16, "1,2,2,2,2"
-if a.config == 5:
+if a.config == 6:
+    from score_based_multimodal_autoencoder_amd.unet_openai import UNetModel  # noqa: E402
+    a.channels, a.hw = 6, 128
+    m = synth.fill_module_(UNetModel(6, 128, 3, 2, (16,), 0.1, (1, 2, 2, 3, 4), num_heads=8).eval()).cuda()
+    eng = m._engine_for(a.batch, a.hw, a.hw, False)
+elif a.config == 5:
     from score_based_multimodal_autoencoder_amd.unet_openai import UNetModel  # noqa: E402
     a.batch, a.channels, a.hw = 64, 3, 16
     m = synth.fill_module_(UNetModel(3, 128, 3, 2, (), 0.1, (1, 2, 4, 8), num_heads=1, use_z=True, z_dim=512).eval()).cuda()
@@ -36,7 +41,7 @@ else:
     eng = m._engine_for(a.batch, a.hw, a.hw)
 x = torch.randn(a.batch, a.channels, a.hw, a.hw, device="cuda")
 t = torch.rand(a.batch, device="cuda")
-out = torch.empty_like(x)
+out = torch.empty((a.batch, 3 if a.config == 6 else a.channels, a.hw, a.hw), device="cuda")
 n = eng.info["n_ops"]
 ms = (ctypes.c_double * n)()
 fl = (ctypes.c_double * n)()
