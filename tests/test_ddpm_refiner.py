@@ -112,3 +112,34 @@ def test_refiner_loop_matches_reference_golden(golden):
     y1 = evaluate_diff_vae(torch.from_numpy(g["vae_out"]).cuda(), sm_model, "cuda", timesteps=50, seed=3)
     y2 = evaluate_diff_vae(torch.from_numpy(g["vae_out"]).cuda(), sm_model, "cuda", timesteps=50, seed=3)
     assert torch.isfinite(y1).all() and torch.equal(y1, y2)
+
+
+@pytest.mark.gpu
+def test_refiner_real_network_at_128x128_matches_oracle_and_loop_runs():
+    """The refiner's REAL network (eval_lat_celeba_hq_all.py:448): UNetModel(img_ch*2 = 6, 128, 3, 2, attention_resolutions=(16,), 0.1,
+    channel_mult=(1,2,2,3,4), num_heads=8) on 128x128 images -- 95 M parameters, 155 GFLOP per image and evaluation, attention with
+    8 heads of 64 channels over the 8x8 level.  One evaluation of two images against the numpy oracle (the oracle takes ~5 s per
+    image on the host), then a few steps of the DDPM loop around it: finite, deterministic, shards reproduce their rows."""
+    import torch
+    from oracle import unet_openai as OU
+    from score_based_multimodal_autoencoder_amd.diffuse_vae import evaluate_diff_vae
+    from score_based_multimodal_autoencoder_amd.unet_openai import UNetModel
+    kw = dict(in_channels=6, model_channels=128, out_channels=3, num_res_blocks=2, attention_resolutions=(16,), channel_mult=(1, 2, 2, 3, 4))
+    m = synth.fill_module_(UNetModel(6, 128, 3, 2, (16,), 0.1, (1, 2, 2, 3, 4), num_heads=8).eval()).cuda()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    x = synth.noise(3, 0, (2, 6, 128, 128))
+    t = np.array([999, 3], np.float32)
+    want = OU.unet_openai_forward(sd, x, t, num_heads=8, **kw)
+    got = m(torch.from_numpy(x).cuda(), torch.from_numpy(t).cuda()).cpu().numpy()
+    assert_close(got, want, 1e-4, REAL_NET_ATOL * float(np.abs(want).max()), "UNetModel(6->3) at 128x128")
+    vae_out = torch.from_numpy(synth.noise(4, 0, (4, 3, 128, 128))).cuda()
+    sm = lambda xx, tt: 0.1 * m(xx, tt)
+    y = evaluate_diff_vae(vae_out, sm, "cuda", timesteps=3, seed=11)
+    y2 = evaluate_diff_vae(vae_out, sm, "cuda", timesteps=3, seed=11)
+    assert torch.isfinite(y).all() and torch.equal(y, y2)
+    h = evaluate_diff_vae(vae_out[2:], sm, "cuda", timesteps=3, seed=11, sample_offset=2)
+    assert torch.equal(h, y[2:]), "a shard keyed by its global sample offset reproduces its rows"
+    m.release_engines()
+
+
+REAL_NET_ATOL = 1e-5       # of max|y|, the per-forward tolerance of every other network (measured 3.6e-6: tools/refiner_check.py)
