@@ -30,7 +30,7 @@ namespace {
 
 DEVINL float chain_act(int act, float v) {
   switch (act) {
-    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_GELU: return 0.5f * v * (1.0f + sbm_erf(v * 0.70710678118654752440f));
     case ACT_LRELU02: return v >= 0.f ? v : 0.2f * v;
     case ACT_RELU: return fmaxf(v, 0.f);
     case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));

@@ -39,7 +39,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 DEVINL float act_apply(int act, float v) {
   switch (act) {
-    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_GELU: return 0.5f * v * (1.0f + sbm_erf(v * 0.70710678118654752440f));
     case ACT_LRELU02: return v >= 0.f ? v : 0.2f * v;
     case ACT_RELU: return fmaxf(v, 0.f);
     case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
@@ -685,6 +685,77 @@ __global__ __launch_bounds__(256) void dwconv7_t8_kernel(const DwArgs d) {
       for (int i = 0; i < C4; ++i) { ss += red[tid * C4 + i].x; qq += red[tid * C4 + i].y; }
       d.stat[(long long)tid * d.B + b] = make_float2(ss, qq);
     }
+  }
+}
+
+// 16 x 16 variant: one workgroup per (sample, 32-channel slab) stages the slab of the sample's image (256 pixels x 8 channel quads,
+// 32 KB) and the 49 x 8 weight quads in LDS; a thread owns (channel quad, output row, half row = 8 outputs) and walks the window rows:
+// 11 pixel + 7 weight LDS reads feed 8 outputs x 7 taps.  GroupNorm partial sums are per (pixel, slab) -- DwOp::stat_slabs, the
+// consumer just sees more partials -- reduced over the slab's 8 quads by wave shuffles.  Taps accumulate in (ky, kx) order as in
+// dwconv7_kernel.
+__global__ __launch_bounds__(256) void dwconv7_t16_kernel(const DwArgs d) {
+  constexpr int RP = 16 * 8 + 1;                    // float4 pitch of an image row in LDS (+1: rows of one wave spread over the banks)
+  __shared__ __attribute__((aligned(16))) float4 tile[16 * RP];
+  __shared__ __attribute__((aligned(16))) float4 wt[49 * 8];
+  const int b = blockIdx.x, slab = blockIdx.y, tid = threadIdx.x;
+  const int cbase = slab * 32;
+  const int nq = min(8, (d.C - cbase) >> 2);        // channel quads of this slab (the last slab may be narrower)
+  for (int idx = tid; idx < 256 * 8; idx += 256) {
+    const int p = idx >> 3, q = idx & 7;
+    if (q < nq) tile[(p >> 4) * RP + (p & 15) * 8 + q] = *reinterpret_cast<const float4*>(d.in + ((long long)p * d.B + b) * d.ldi + cbase + 4 * q);
+  }
+  for (int idx = tid; idx < 49 * 8; idx += 256) if ((idx & 7) < nq) wt[idx] = *reinterpret_cast<const float4*>(d.w + (long long)(idx >> 3) * d.C + cbase + 4 * (idx & 7));
+  __syncthreads();
+  const int q = tid & 7, oy = (tid >> 3) & 15, half = tid >> 7;
+  const bool live = q < nq;
+  const int ox0 = half * 8;
+  float4 acc[8];
+#pragma unroll
+  for (int o = 0; o < 8; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ky0 = max(0, 3 - oy), ky1 = live ? min(7, 16 + 3 - oy) : 0;
+  for (int ky = ky0; ky < ky1; ++ky) {
+    const int iy = oy - 3 + ky;
+    float4 x[14], w[7];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) {                  // window columns ox0 - 3 + j; columns outside the image are never used below
+      const int ix = min(max(ox0 - 3 + j, 0), 15);
+      x[j] = tile[iy * RP + ix * 8 + q];
+    }
+#pragma unroll
+    for (int kx = 0; kx < 7; ++kx) w[kx] = wt[(ky * 7 + kx) * 8 + q];
+#pragma unroll
+    for (int o = 0; o < 8; ++o)
+#pragma unroll
+      for (int kx = 0; kx < 7; ++kx) {
+        const int ix = ox0 + o - 3 + kx;
+        if (ix >= 0 && ix < 16) {
+          const float4 xv = x[o + kx];
+          acc[o].x = fmaf(xv.x, w[kx].x, acc[o].x); acc[o].y = fmaf(xv.y, w[kx].y, acc[o].y);
+          acc[o].z = fmaf(xv.z, w[kx].z, acc[o].z); acc[o].w = fmaf(xv.w, w[kx].w, acc[o].w);
+        }
+      }
+  }
+  const int c = cbase + 4 * (live ? q : 0);
+  const float4 bi = live ? *reinterpret_cast<const float4*>(d.bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d.cond && live) cv = *reinterpret_cast<const float4*>(dw_cond_row(d, b) + c);
+  float s = 0.f, qq = 0.f;
+#pragma unroll
+  for (int o = 0; o < 8; ++o) {
+    acc[o].x += bi.x; acc[o].y += bi.y; acc[o].z += bi.z; acc[o].w += bi.w;
+    if (d.cond) { acc[o].x += cv.x; acc[o].y += cv.y; acc[o].z += cv.z; acc[o].w += cv.w; }
+    const int p = oy * 16 + ox0 + o;
+    if (live) *reinterpret_cast<float4*>(d.out + ((long long)p * d.B + b) * d.ldo + c) = acc[o];
+    s += (acc[o].x + acc[o].y) + (acc[o].z + acc[o].w);
+    qq += (acc[o].x * acc[o].x + acc[o].y * acc[o].y) + (acc[o].z * acc[o].z + acc[o].w * acc[o].w);
+  }
+  if (d.stat) {                                     // ONE partial per (slab, sample): the workgroup holds all 256 pixels of its 32 channels
+    __shared__ float2 red[4];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m); qq += __shfl_xor(qq, m); }
+    if ((tid & 63) == 0) red[tid >> 6] = make_float2(s, qq);
+    __syncthreads();
+    if (tid == 0) d.stat[(long long)slab * d.B + b] = make_float2((red[0].x + red[1].x) + (red[2].x + red[3].x), (red[0].y + red[1].y) + (red[2].y + red[3].y));
   }
 }
 
@@ -1375,6 +1446,42 @@ __global__ __launch_bounds__(256) void attn_qkv_kernel(const AttnQkvArgs a) {
   }
 }
 
+// Few tokens (T <= 8: the 2x2 / 1x1 middle block with one wide head): one block reduction over the channels per logit, T*T logits.
+__global__ __launch_bounds__(256) void attn_qkv_small_kernel(const AttnQkvArgs a) {
+  __shared__ float w[64 * 64];
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+  const float* base = a.qkv + (long long)b * a.ldq + h * 3 * a.chh;
+  const long long ts = (long long)a.B * a.ldq;
+  const float s2 = a.scale * a.scale;
+  for (int pair = 0; pair < a.T * a.T; ++pair) {
+    const int t = pair / a.T, u = pair - t * a.T;
+    float acc = 0.f;
+    for (int c = tid; c < a.chh; c += 256) acc = fmaf(base[t * ts + c], base[u * ts + a.chh + c], acc);
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    if (tid == 0) w[pair] = red[0] * s2;
+    __syncthreads();
+  }
+  if (tid < a.T) {
+    float m = -INFINITY;
+    for (int u = 0; u < a.T; ++u) m = fmaxf(m, w[tid * a.T + u]);
+    float z = 0.f;
+    for (int u = 0; u < a.T; ++u) { const float e = expf(w[tid * a.T + u] - m); w[tid * a.T + u] = e; z += e; }
+    const float inv = 1.0f / z;
+    for (int u = 0; u < a.T; ++u) w[tid * a.T + u] *= inv;
+  }
+  __syncthreads();
+  for (int c = tid; c < a.chh; c += 256)
+    for (int t = 0; t < a.T; ++t) {
+      float acc = 0.f;
+      for (int u = 0; u < a.T; ++u) acc = fmaf(w[t * a.T + u], base[u * ts + 2 * a.chh + c], acc);
+      a.out[((long long)t * a.B + b) * a.ldo + h * a.chh + c] = acc;
+    }
+}
+
 // rowpack: element (y, x, c) goes to row y, channel x*Cv + c of a [Ho][B][ld] tensor (init_conv's row-packed input)
 __global__ void nchw_to_pbc_kernel(const float* in, float* out, int B, int C, int Hn, int Wn, int pad_y, int pad_x, int Ho, int Wo, int ld, int Cv, int rowpack) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1473,7 +1580,7 @@ DwArgs make_dw_args(const Plan& plan, const DwOp& o, const float* prm, float* ws
   d.in = ws + o.in.off; d.out = ws + o.out.off; d.w = prm + o.w_off; d.bias = prm + o.bias_off;
   d.cond = o.has_cond ? ws + o.cond_off : nullptr; d.stat = o.stat_off >= 0 ? reinterpret_cast<float2*>(ws + o.stat_off) : nullptr;
   d.B = o.B; d.H = o.in.H; d.W = o.in.W; d.C = o.in.C; d.ldi = o.in.ld; d.ldo = o.out.ld; d.cond_ld = o.cond_ld;
-  d.lanes = o.in.C / 4 < 256 ? o.in.C / 4 : 256; d.spb = 256 / d.lanes;
+  d.lanes = o.in.C / 4 < 256 ? o.in.C / 4 : 256; d.spb = 256 / d.lanes; d.slabs = o.stat_slabs;
   return d;
 }
 AttnArgs make_attn_args(const AttnOp& o, float* ws) {
@@ -1516,7 +1623,10 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
     case OP_GEMM: return launch_gemm(op.g, dp.hot[idx], ext_in, ext_out, st);
     case OP_DWCONV7: {
       const DwOp& o = op.dw; const DwArgs d = make_dw_args(plan, o, prm, ws, dp.ctl);
-      if (o.in.W == 8 && o.in.H == 8 && o.in.C / 4 <= 32 && !getenv("SBM_NO_DWT8")) {
+      if (o.stat_slabs > 1) {                       // plan-time choice (16 x 16, channels a multiple of 32): the statistics layout depends on it
+        if (o.in.W != 16 || o.in.H != 16 || (o.in.C + 31) / 32 != o.stat_slabs || (o.in.C & 3)) return "dwconv7: slab statistics need a 16x16 tensor in slabs of 32 channels";
+        SBM_KLAUNCH(dwconv7_t16_kernel, dim3(o.B, o.stat_slabs), dim3(256), 0, st, d);
+      } else if (o.in.W == 8 && o.in.H == 8 && o.in.C / 4 <= 32 && !getenv("SBM_NO_DWT8")) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_t8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
         SBM_KLAUNCH(dwconv7_t8_kernel, dim3(o.B), dim3(256), (size_t)(64 + 49) * (o.in.C / 4) * 16, st, d);
@@ -1598,7 +1708,8 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       const AttnQkvOp& o = op.aq; AttnQkvArgs a{};
       a.qkv = ws + o.qkv.off; a.out = ws + o.out.off; a.B = o.B; a.T = o.qkv.H * o.qkv.W; a.ldq = o.qkv.ld; a.ldo = o.out.ld; a.heads = o.heads; a.chh = o.chh; a.scale = o.scale;
       if (a.T > 64) return "attention: more than 64 positions";
-      SBM_KLAUNCH(attn_qkv_kernel, dim3(o.B * o.heads), dim3(256), 0, st, a);
+      if (a.T <= 8) SBM_KLAUNCH(attn_qkv_small_kernel, dim3(o.B * o.heads), dim3(256), 0, st, a);
+      else SBM_KLAUNCH(attn_qkv_kernel, dim3(o.B * o.heads), dim3(256), 0, st, a);
     } break;
     default: return "unknown op";
   }

@@ -502,7 +502,9 @@ BlockIO emit_convnext(Builder& b, const std::string& pre, const View& x, const C
   const int H = x.H, W = x.W, P = H * W;
   // depthwise 7x7 + bias + time condition -> h0, GroupNorm partials
   View h0; h0.H = H; h0.W = W; h0.C = x.C; h0.ld = x.C; h0.off = b.ws_alloc((int64_t)P * b.B * h0.ld, b.in_chain(P));
-  int64_t st0 = b.new_stats(P, b.in_chain(P));
+  static const bool dw_slabs_on = !getenv("SBM_NO_DWT16");
+  const int slabs = (dw_slabs_on && H == 16 && W == 16 && x.C > 32 && !b.in_chain(P)) ? (x.C + 31) / 32 : 1;      // the last slab may be narrower
+  int64_t st0 = b.new_stats(slabs > 1 ? slabs : P, b.in_chain(P));       // per pixel, or (16x16 slab kernel) per 32-channel slab
   {
     Op& op = b.push(OP_DWCONV7, pre + "ds_conv");
     if (b.chain_pix > 0 && P <= b.chain_pix) op.chain = 1;
@@ -514,7 +516,7 @@ BlockIO emit_convnext(Builder& b, const std::string& pre, const View& x, const C
     d.w_off = b.add_params(wp);
     d.bias_off = b.add_params(b.pack_vec(b.T(pre + "ds_conv.bias", cin), cin, &cm, x.C));
     d.has_cond = has_time ? 1 : 0; d.cond_off = cond_off; d.cond_ld = cond_ld;
-    d.stat_off = st0;
+    d.stat_off = st0; d.stat_slabs = slabs;
     b.plan->flops_dense += 2.0 * b.B * cin * 49.0 * P;
     b.plan->flops_exec += 2.0 * b.B * x.C * 49.0 * P;
   }
@@ -523,7 +525,7 @@ BlockIO emit_convnext(Builder& b, const std::string& pre, const View& x, const C
   c1.name = pre + "net.1"; c1.a = h0; c1.cm = cm; c1.cin_true = cin; c1.kh = c1.kw = 3; c1.pad = 1;
   c1.w = b.T(pre + "net.1.weight", (int64_t)cout * mult * cin * 9); c1.bias = b.T(pre + "net.1.bias", cout * mult);
   c1.cout = cout * mult; c1.Hout = H; c1.Wout = W;
-  c1.gn = true; c1.gn_part = st0; c1.gn_nparts = P; c1.gn_inv = 1.0f / ((float)cin * P);
+  c1.gn = true; c1.gn_part = st0; c1.gn_nparts = slabs > 1 ? slabs : P; c1.gn_inv = 1.0f / ((float)cin * P);
   c1.gamma = b.T(pre + "net.0.weight", cin); c1.beta = b.T(pre + "net.0.bias", cin);
   c1.act = ACT_GELU; c1.want_stats = true;
   Builder::ConvResult r1 = b.emit_conv(c1);

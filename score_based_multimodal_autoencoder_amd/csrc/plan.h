@@ -106,7 +106,9 @@ struct DwOp {
   int has_cond = 0;
   int64_t cond_off = 0;   // workspace [B][cond_ld] (+channel offset)
   int cond_ld = 0;
-  int64_t stat_off = -1;  // workspace float2 [P][B]
+  int64_t stat_off = -1;  // workspace float2 [P][B], or [stat_slabs][B] when stat_slabs > 1
+  int stat_slabs = 1;     // > 1: ONE partial per slab of 32 channels (all pixels), the last slab possibly narrower (16x16 level:
+                          // dwconv7_t16_kernel's workgroups are (sample, slab)); stat_slabs = ceil(C / 32)
 };
 
 struct AttnOp {           // OP_LINATTN / OP_ATTN

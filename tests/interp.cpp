@@ -108,6 +108,8 @@ static void run_gemm(const GemmOp& g, const float* prm, float* ws, const float* 
 
 static void run_dw(const DwOp& d, const float* prm, float* ws) {
   const int B = d.B, H = d.in.H, W = d.in.W, C = d.in.C;
+  const int slabs = d.stat_slabs > 1 ? d.stat_slabs : 1;          // > 1: one partial per (32-channel slab, sample) over all pixels
+  std::vector<double> ss((size_t)slabs * B, 0.0), qs((size_t)slabs * B, 0.0);
   for (int p = 0; p < H * W; ++p) {
     const int oy = p / W, ox = p % W;
     for (int b = 0; b < B; ++b) {
@@ -123,10 +125,13 @@ static void run_dw(const DwOp& d, const float* prm, float* ws) {
         acc += prm[d.bias_off + c];
         if (d.has_cond) acc += ws[d.cond_off + (int64_t)b * d.cond_ld + c];
         o[c] = acc; s += acc; q += (double)acc * acc;
+        if (slabs > 1) { ss[(size_t)(c / 32) * B + b] += acc; qs[(size_t)(c / 32) * B + b] += (double)acc * acc; }
       }
-      if (d.stat_off >= 0) { ws[d.stat_off + ((int64_t)p * B + b) * 2] = (float)s; ws[d.stat_off + ((int64_t)p * B + b) * 2 + 1] = (float)q; }
+      if (d.stat_off >= 0 && slabs == 1) { ws[d.stat_off + ((int64_t)p * B + b) * 2] = (float)s; ws[d.stat_off + ((int64_t)p * B + b) * 2 + 1] = (float)q; }
     }
   }
+  if (d.stat_off >= 0 && slabs > 1)
+    for (int i = 0; i < slabs * B; ++i) { ws[d.stat_off + (int64_t)i * 2] = (float)ss[i]; ws[d.stat_off + (int64_t)i * 2 + 1] = (float)qs[i]; }
 }
 
 static void run_attn(const AttnOp& a, bool linear, float* ws) {
