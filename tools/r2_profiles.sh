@@ -1,4 +1,4 @@
-# Round-2 measurement run (one GPU box): bench lines of configs 2/4/5, rocprofv3 kernel stats of the config-2 bench, and the PMC passes
+# Round-2 measurement run (one GPU box): bench lines of configs 2/4/5, rocprofv3 kernel stats of the same bench commands, and the PMC passes
 # (traffic: FETCH_SIZE / WRITE_SIZE; SQ counters) of eager forwards, each counter set in a run of its own with --kernel-trace only.
 set -x
 export PYTHONUNBUFFERED=1
@@ -15,9 +15,11 @@ for C in ${CONFIGS:-2 4 5}; do
   mkdir -p profiles && cp $O/r02_c${C}_traffic.json $O/r02_c${C}_sq_counters.json profiles/
   rm -rf $O/pmc_fetch_c$C $O/pmc_write_c$C $O/pmc_sq1_c$C $O/pmc_sq2_c$C
 done
-rocprofv3 --kernel-trace --stats -d $O/prof_bench -o t --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_prof.json 2> $O/bench_prof.err || echo "bench profile failed"
-cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/r02_bench_kernel_stats.csv
-rm -rf $O/prof_bench
+for C in ${CONFIGS:-2 4 5}; do
+  rocprofv3 --kernel-trace --stats -d $O/prof_bench_c$C -o t --output-format csv -- python3 bench.py --config $C --steps $([ $C = 2 ] && echo 3 || echo 1) --warmup 1 --no-cpu-baseline > $O/bench_prof_c$C.json 2> $O/bench_prof_c$C.err || echo "bench profile failed c$C"
+  cp $(find $O/prof_bench_c$C -name "*kernel_stats.csv" | head -1) $O/r02_bench_c${C}_kernel_stats.csv
+  rm -rf $O/prof_bench_c$C
+done
 for C in ${CONFIGS:-2 4 5}; do
   python3 bench.py --config $C --steps $([ $C = 2 ] && echo 20 || echo 3) --warmup 1 > $O/r02_bench_c$C.json 2> $O/r02_bench_c$C.err || echo "bench c$C failed"
   tail -2 $O/r02_bench_c$C.err
