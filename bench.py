@@ -90,11 +90,9 @@ def cpu_model():
 
 
 def lib_hash():
+    """Identity of the kernels: hash of the library's SOURCES (reproducible across rebuilds; see _lib.source_hash)."""
     from score_based_multimodal_autoencoder_amd import _lib
-    h = hashlib.sha256()
-    with open(_lib.LIB_PATH, "rb") as fh:
-        h.update(fh.read())
-    return h.hexdigest()[:16]
+    return _lib.source_hash()
 
 
 def build_models(cfg, device):

@@ -46,6 +46,17 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+def source_hash():
+    """Identity of the kernels a measurement was taken on: sha256 over the library's sources and headers (the binary's own bytes are
+    not reproducible across rebuilds, the sources are).  Stamped into the committed profile summaries and checked by bench.py."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> csrc/libsbmae_hip.so (cross-compiles without a GPU)."""
     if not force and not needs_build():

@@ -37,4 +37,4 @@ for name, ctrs in sorted(acc.items()):
         e["lds_bank_conflict_frac"] = round(e["SQ_LDS_BANK_CONFLICT"] / e["SQ_LDS_IDX_ACTIVE"], 4)
     out[name] = e
 from score_based_multimodal_autoencoder_amd import _lib
-print(json.dumps({"lib_hash": hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16], "kernels": out}, indent=1))
+print(json.dumps({"lib_hash": _lib.source_hash(), "kernels": out}, indent=1))

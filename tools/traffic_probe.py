@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 
 def lib_hash():
     from score_based_multimodal_autoencoder_amd import _lib
-    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+    return _lib.source_hash()
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "--summarise":
