@@ -221,6 +221,8 @@ int sbm_debug_chain_sync(sbm_model* m, unsigned* out, int n_words);
 int sbm_debug_chain_ctl(sbm_model* m, unsigned spin_limit, int skip_arrive);   /* barrier poll limit (0 = default); 1 = force a barrier time-out */
 int sbm_debug_chain_stamps(sbm_model* m, int first, int count, unsigned long long* out_host);
 int sbm_debug_row_stamps(sbm_model* m, int first, int count, unsigned long long* out_host, int* kinds, int cap, int* n_out);
+/* the same for a run of pixel-kernel ops (csrc/pixrun.hip: the 4x4 / 2x2 levels as sample-owned workgroups); kinds[i] = op kind * 1000 + taps */
+int sbm_debug_pix_stamps(sbm_model* m, int first, int count, unsigned long long* out_host, int* kinds, int cap, int* n_out);
 int sbm_debug_gemm_stamps(sbm_model* m, const float* in_dev, float* out_dev, int i, unsigned long long* stamps_host);
 int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps,
                           double* ms_per_op, double* flops_per_op, int n_ops);

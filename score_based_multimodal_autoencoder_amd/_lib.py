@@ -11,7 +11,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsbmae_hip.so")
-SOURCES = ["plan.cpp", "kernels.hip", "chain.hip", "rowrun.hip", "sampler.hip", "guidance.hip", "fid.hip", "api.hip"]
+SOURCES = ["plan.cpp", "kernels.hip", "chain.hip", "rowrun.hip", "pixrun.hip", "sampler.hip", "guidance.hip", "fid.hip", "api.hip"]
 HEADERS = ["plan.h", "device.h", os.path.join("..", "..", "include", "sbmae.h")]
 
 SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA, SBM_MLP, SBM_RESENC, SBM_ATTRENC, SBM_CLG = 0, 1, 2, 3, 4, 5, 6, 7
@@ -21,7 +21,7 @@ OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "n
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
            "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step", "sbm_langevin_norms", "sbm_langevin_update", "sbm_clg_forward", "sbm_clg_guide",
            "sbm_fill_normal", "sbm_sampler_run", "sbm_cond_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
-           "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_ctl", "sbm_debug_chain_stamps", "sbm_debug_row_stamps",
+           "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_ctl", "sbm_debug_chain_stamps", "sbm_debug_row_stamps", "sbm_debug_pix_stamps",
            "sbm_ddpm_step", "sbm_fid_accumulate", "sbm_fid_finalize_stats", "sbm_fid_work_doubles", "sbm_fid_frechet", "sbm_debug_dgemm_tn"]
 
 
@@ -122,6 +122,7 @@ def lib():
         L.sbm_debug_chain_sync.argtypes = [vp, ctypes.POINTER(ctypes.c_uint), i]
         L.sbm_debug_chain_ctl.argtypes = [vp, ctypes.c_uint, i]
         L.sbm_debug_row_stamps.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_uint64), ip, i, ip]
+        L.sbm_debug_pix_stamps.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_uint64), ip, i, ip]
         L.sbm_debug_chain_stamps.argtypes = [vp, i, i, ctypes.POINTER(ctypes.c_uint64)]
         L.sbm_debug_profile_ops.argtypes = [vp, vp, vp, vp, i, ctypes.POINTER(dbl), ctypes.POINTER(dbl), i]
         L.sbm_ddpm_step.argtypes = [vp, vp, vp, vp, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, i, ctypes.c_long, u64, u64, i, vp]

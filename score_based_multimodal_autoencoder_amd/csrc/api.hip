@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -123,6 +124,7 @@ void sbm_model_destroy(sbm_model* m) {
   // chain kernel may still write) may be released under a kernel in flight
   (void)hipDeviceSynchronize();
   rowrun_release(&m->plan);
+  pixrun_release(&m->plan);
   if (m->own) (void)hipStreamSynchronize(m->own);
   if (m->d_params) (void)hipFree(m->d_params);
   if (m->d_ws) (void)hipFree(m->d_ws);
@@ -269,6 +271,13 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
       unsigned* dev_view = nullptr;
       if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_view), m->h_abort, 0)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipHostGetDevicePointer", e); }
       m->dp.chain_ctl.abort_host = dev_view;
+      // SBM_PIX=1 (opt-in, experimental): the same ops as sample-owned workgroups (pixrun.hip).  Programs are built here; anything the
+      // pixel kernel cannot take (shapes, LDS) leaves ALL of them to the chain kernel -- decided once, never at launch time.
+      if (std::getenv("SBM_PIX")) {
+        const char* pe = pixrun_prepare(m->dp);
+        if (pe) { pixrun_release(&m->plan); if (std::getenv("SBM_PIX_VERBOSE")) fprintf(stderr, "sbmae: chain-level ops stay in the chain kernel: %s\n", pe); }
+        else m->dp.use_pix = true;
+      }
     }
   }
   if (kind == SBM_UNET || kind == SBM_UNET_OA) {
@@ -432,6 +441,29 @@ int sbm_debug_row_stamps(sbm_model* m, int first, int count, unsigned long long*
   }
   const int n = rowrun_program_ops(m->dp, first, count, kinds, cap);
   if (n < 0 || n + 1 > 256) { (void)hipFree(d); return fail("sbm_debug_row_stamps: no such program"); }
+  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (n + 1 < cap ? n + 1 : cap), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  *n_out = n;
+  return 0;
+}
+
+// the same for the pixel kernel (pixrun.hip): stamps of workgroup 0 at the start of every program op of the run [first, first + count)
+int sbm_debug_pix_stamps(sbm_model* m, int first, int count, unsigned long long* out_host, int* kinds, int cap, int* n_out) {
+  if (!m || !out_host || !kinds || !n_out || cap <= 0) return fail("sbm_debug_pix_stamps: bad arguments");
+  if (!m->dp.use_pix) return fail("sbm_debug_pix_stamps: the pixel kernel is not in use for this model");
+  for (int i = first; i < first + count; ++i) if (i < 0 || i >= (int)m->plan.ops.size() || !m->plan.ops[i].chain || m->plan.ops[i].time_path) return fail("sbm_debug_pix_stamps: not a run of pixel-kernel ops");
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 256));
+  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 256));
+  for (int rep = 0; rep < 3; ++rep) {
+    g_pix_dbg = d;
+    const char* e = launch_pixrun(m->dp, first, count, m->own);
+    g_pix_dbg = nullptr;
+    if (e) { (void)hipFree(d); return fail(e); }
+    HIPCHK(hipStreamSynchronize(m->own));
+  }
+  const int n = pixrun_program_ops(m->dp, first, count, kinds, cap);
+  if (n < 0 || n + 1 > 256) { (void)hipFree(d); return fail("sbm_debug_pix_stamps: no such program"); }
   HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (n + 1 < cap ? n + 1 : cap), hipMemcpyDeviceToHost));
   (void)hipFree(d);
   *n_out = n;

@@ -142,7 +142,14 @@ struct DevPlan {
   int chain_grid = 256, chain_block = 512;
   ChainCtl chain_ctl{};
   const StepCtl* ctl = nullptr;         // sampler control block (score nets)
+  bool use_pix = false;                 // the chain-level ops run as sample-owned workgroups (pixrun.hip) instead of the chain kernel
 };
+// pixrun.hip: the 4x4 / 2x2 levels, one sample per workgroup, activations in LDS
+const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st);
+const char* pixrun_prepare(const DevPlan& dp);
+void pixrun_release(const Plan* plan);
+extern unsigned long long* g_pix_dbg;
+int pixrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap);   // diagnostics: kind * 1000 + taps per program op
 const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st);
 const char* chain_launch_geometry(int cus, int* grid, int* block);   // verifies that the whole grid can be resident
 int chain_variant_groups();

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -404,7 +405,10 @@ class Builder {
                         ((P_out_px <= row_pix && P_in_px <= 4 * row_pix) || (P_in_px <= row_pix && P_out_px <= 4 * row_pix)) && P_in_px <= 4 && P_out_px <= 4;
     {
       std::vector<float> packed = pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, g.Kp, g.Npad, s.transposed, s.out_scale, s.gn ? s.gamma : nullptr);
-      if (row_op) g.wt_off = add_transposed(packed, s.kh * s.kw, g.Npad, g.Kp);
+      // row-kernel ops and (pixrun.hip) the chain-level ops also keep a transposed copy [tap][Kp][Npad]
+      const bool pix_on = getenv("SBM_PIX") != nullptr;      // opt-in (read per plan, like SBM_CHAIN_PIX)
+      const bool pix_op = pix_on && chain_pix > 0 && P_out_px <= chain_pix && !s.out_nchw;
+      if (row_op || pix_op) g.wt_off = add_transposed(packed, s.kh * s.kw, g.Npad, g.Kp);
       g.w_off = add_params(packed);
     }
     std::vector<double> bias(g.Npad, 0.0);
@@ -442,7 +446,7 @@ class Builder {
       g.has2 = 1; g.a2 = s.a2; g.up2 = s.up2;
       g.Kp2 = round_up(s.a2.C, 32);
       std::vector<float> packed2 = pack_conv(s.w2, s.cout, s.cin2, 1, 1, s.cm2, g.Kp2, g.Npad, false, nullptr);
-      if (row_op) g.wt2_off = add_transposed(packed2, 1, g.Npad, g.Kp2);
+      if (row_op || (getenv("SBM_PIX") != nullptr && chain_pix > 0 && P_out_px <= chain_pix && !s.out_nchw)) g.wt2_off = add_transposed(packed2, 1, g.Npad, g.Kp2);
       g.w2_off = add_params(packed2);
       if (s.bias2) { for (int n = 0; n < s.cout; ++n) bias[n] += s.bias2[n]; any_bias = true; }
     }
@@ -954,6 +958,17 @@ void finalize_gemm_tables(Plan* plan) {
         max_part = std::max<int64_t>(max_part, (int64_t)tiles * S * g.BM * g.BN);
         max_tiles = std::max<int64_t>(max_tiles, tiles);
       }
+    }
+  }
+  if (getenv("SBM_DUMP_PLAN")) {                       // diagnostics: one line per op
+    int i = 0;
+    for (const Op& op : plan->ops) {
+      int P = 0, C = 0, N = 0;
+      if (op.kind == OP_GEMM) { P = op.g.Hout * op.g.Wout; C = op.g.a.C; N = op.g.out.C; }
+      else if (op.kind == OP_DWCONV7) { P = op.dw.in.H * op.dw.in.W; C = op.dw.in.C; }
+      else if (op.kind == OP_LINATTN || op.kind == OP_ATTN) { P = op.at.qkv.H * op.at.qkv.W; C = op.at.qkv.C; N = op.at.out.C; }
+      else if (op.kind == OP_GN_RES) { P = op.gr.u.H * op.gr.u.W; C = op.gr.u.C; }
+      fprintf(stderr, "op %3d kind %2d %s%s%s P %3d C %4d N %4d  %s\n", i++, op.kind, op.chain ? "chain " : "", op.row ? "row " : "", op.time_path ? "time " : "", P, C, N, op.name.c_str());
     }
   }
   if (max_tiles > 0) {

@@ -389,6 +389,40 @@ def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
     assert torch.isfinite(outs["16"]).all()
 
 
+def test_pixel_kernel_matches_per_layer_kernels_at_bench_size(pkg):
+    """SBM_PIX=1 (opt-in): the 4x4 / 2x2 levels as sample-owned workgroups (csrc/pixrun.hip: one sample per workgroup, activations in
+    LDS, pixels on the MFMA rows) against one launch per layer, config-2 score net at B = 256; and a 20-step sampler run through it."""
+    import ctypes
+    import os
+    from score_based_multimodal_autoencoder_amd.sde_helper2 import VPSDE, uncond_sampler
+    m = _unet(pkg, "P5")
+    x = torch.randn(256, 5, 8, 8, device="cuda")
+    t = torch.rand(256, device="cuda")
+    sde = VPSDE(0.1, 5.0, 20)
+    outs, runs = {}, {}
+    for tag, env in (("layers", {"SBM_CHAIN_PIX": "0"}), ("pix", {"SBM_CHAIN_PIX": "16", "SBM_PIX": "1"})):
+        os.environ.update(env)
+        try:
+            m.release_engines()
+            for _ in range(2):
+                y = m(x, t)
+            outs[tag] = y.clone()
+            if tag == "pix":
+                eng = m._engine_for(256, 8, 8)
+                st = (ctypes.c_uint64 * 256)(); kinds = (ctypes.c_int * 256)(); nout = ctypes.c_int(0)
+                L = pkg["lib"].lib()
+                active = [i for i in range(eng.info["n_ops"]) if L.sbm_debug_pix_stamps(eng.h, i, 1, st, kinds, 256, ctypes.byref(nout)) == 0]
+                assert len(active) >= 40, "the pixel kernel must be the one that ran the low-resolution ops"
+            runs[tag] = uncond_sampler((256, 5, 8, 8), m, "cuda", sde, x0=x, seed=5).clone()
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+            m.release_engines()
+    scale = float(outs["layers"].abs().max())
+    assert float((outs["layers"] - outs["pix"]).abs().max()) <= 2e-5 * scale
+    assert float((runs["layers"] - runs["pix"]).abs().max()) <= 1e-4 * float(runs["layers"].abs().max())
+
+
 def test_full_size_sampling_run_is_path_and_shard_independent(pkg):
     """BASELINE config 2 at full size (B = 256, 1000 reverse-SDE steps, in-kernel Philox noise): the samples do not depend on
     WHICH kernels carry the low-resolution levels (XCD-resident chain vs one launch per layer) beyond float32 reassociation, nor
