@@ -464,7 +464,7 @@ int sbm_debug_pix_stamps(sbm_model* m, int first, int count, unsigned long long*
   }
   const int n = pixrun_program_ops(m->dp, first, count, kinds, cap);
   if (n < 0 || n + 1 > 256) { (void)hipFree(d); return fail("sbm_debug_pix_stamps: no such program"); }
-  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (n + 1 < cap ? n + 1 : cap), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (cap < 256 ? cap : 256), hipMemcpyDeviceToHost));      // op stamps [0, n], phase stamps from 64
   (void)hipFree(d);
   *n_out = n;
   return 0;

@@ -216,6 +216,8 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       continue;
     }
     // ---------------------------------------------------------------- GEMM
+#define PSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && k < 30) dbg[64 + k * 6 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+    PSTAMP(0);
     for (int i = tid; i < op.tap_cnt * P_TAP_I; i += PNT) tapl[i] = reinterpret_cast<const int*>(op.taps + op.tap_first)[i];
     __syncthreads();
     const bool gn = op.gn_stat >= 0;
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       };
 #pragma unroll
       for (int r = 0; r < P_RING; ++r) if (r < nk) issue(ring[r]);
+      PSTAMP(1);
       for (int i = 0; i < nk; i += P_RING) {
 #pragma unroll
         for (int r = 0; r < P_RING; ++r) {
@@ -324,11 +327,13 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
           }
         }
       }
+      PSTAMP(2);
       // partials: red[wave][row 4 g + v][column 4 q + i]
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         *reinterpret_cast<float4*>(red + (wave * 16 + 4 * g + v) * 64 + 4 * q) = make_float4(acc[0][v], acc[1][v], acc[2][v], acc[3][v]);
       __syncthreads();
+      PSTAMP(3);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (j < par) {
@@ -366,6 +371,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         }
       }
       __syncthreads();                                    // red (and the taps, after the last pass) are reused
+      PSTAMP(4);
       cb0 += par;
     }
     if (op.stat_out >= 0) {

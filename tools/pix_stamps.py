@@ -28,12 +28,17 @@ while i < n:
 KN = {0: "gemm", 1: "dw", 2: "linattn", 4: "gn_res", 101: "(stage)"}
 for first, last in runs:
     _lib.check(L.sbm_debug_pix_stamps(eng.h, first, last - first + 1, st, kinds, 256, ctypes.byref(nout)))
-    v = list(st)[:nout.value + 1]; k = list(kinds)[:nout.value]
+    full = list(st); v = full[:nout.value + 1]; k = list(kinds)[:nout.value]
     j = first
     print(f"run: ops {first}..{last}")
     for i in range(nout.value):
         kind, taps = k[i] // 1000, k[i] % 1000
         nm = "(stage)" if kind == 101 else names[j]
         if kind != 101: j += 1
-        print(f"  {nm[:52]:52s} {KN.get(kind, kind):8} {(v[i + 1] - v[i]) / 2400.0:8.2f} us" + (f"   {taps} taps" if taps else ""))
+        extra = ""
+        if kind == 0 and i < 30 and os.environ.get("PIX_PHASES"):
+            ph = [full[64 + i * 6 + j] for j in range(5)]
+            if all(ph):
+                extra = "   | taps+sync %.2f  fill %.2f  kloop %.2f  partials+sync %.2f  epilogue+sync %.2f (last pass)" % tuple((b_ - a_) / 2400.0 for a_, b_ in zip([v[i]] + ph[:4], ph))
+        print(f"  {nm[:52]:52s} {KN.get(kind, kind):8} {(v[i + 1] - v[i]) / 2400.0:8.2f} us" + (f"   {taps} taps" if taps else "") + extra)
     print(f"  total {(v[-1] - v[0]) / 2400.0:.1f} us for {nout.value} program ops")
