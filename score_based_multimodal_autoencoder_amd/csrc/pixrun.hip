@@ -79,17 +79,18 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
 
 }  // namespace
 
-__global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict__ ops, int count, int B, int act_floats, unsigned long long* dbg) {
+__global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict__ ops, int count, int B, int act_floats, const PixTap* __restrict__ taps, int ntaps, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* zero = lds + act_floats;                        // P_ZERO_F zeros: the source of rows a tap does not reach
   float* red = zero + P_ZERO_F;                          // [8 waves][16 rows][64 columns]
   float* stat = red + P_RED_F;                           // [slots][2]
   float* scr = stat + P_STAT_SLOTS * 2;                  // scratch (LinearAttention contexts, reductions)
-  int* tapl = reinterpret_cast<int*>(scr + P_SCR_F);     // the op's taps
+  int* tap_all = reinterpret_cast<int*>(scr + P_SCR_F);  // the tap tables of the whole program, staged once
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   const int q = lane & 15, g = lane >> 4;
   for (int i = tid; i < act_floats + P_ZERO_F + P_RED_F; i += PNT) lds[i] = 0.f;
+  for (int i = tid; i < ntaps * P_TAP_I; i += PNT) tap_all[i] = reinterpret_cast<const int*>(taps)[i];
   __syncthreads();
   for (int k = 0; k < count; ++k) {
     const PixOpD& op = ops[k];
@@ -124,10 +125,16 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         for (int p = pg; p < P; p += tpc) {
           const int py = p / d.W, px = p - py * d.W;
           float acc = 0.f;
-          for (int qp = 0; qp < P; ++qp) {
-            const int qy = qp / d.W, qx = qp - qy * d.W;
-            const float w = d.w[((qy - py + 3) * 7 + (qx - px + 3)) * C + c];
-            acc = fmaf(lds[op.in_lds + pix_at(c, qp, op.in_cs)], w, acc);
+          for (int q0 = 0; q0 < P; q0 += 4) {             // P is 4 or 16 (or 1): four independent weight loads in flight
+            float xv[4], wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int qp = min(q0 + j, P - 1), qy = qp / d.W, qx = qp - qy * d.W;
+              wv[j] = d.w[((qy - py + 3) * 7 + (qx - px + 3)) * C + c];
+              xv[j] = lds[op.in_lds + pix_at(c, qp, op.in_cs)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (q0 + j < P) acc = fmaf(xv[j], wv[j], acc);
           }
           acc += bi;
           if (d.cond) acc += cv;
@@ -218,8 +225,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     // ---------------------------------------------------------------- GEMM
 #define PSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && k < 30) dbg[64 + k * 6 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
     PSTAMP(0);
-    for (int i = tid; i < op.tap_cnt * P_TAP_I; i += PNT) tapl[i] = reinterpret_cast<const int*>(op.taps + op.tap_first)[i];
-    __syncthreads();
+    const int* tapl = tap_all + op.tap_first * P_TAP_I;
     const bool gn = op.gn_stat >= 0;
     float mean = 0.f, rstd = 1.f, inv_r = 1.f;
     if (gn) {
@@ -481,10 +487,10 @@ struct PBuilder {
   }
 };
 
-struct PProgram { PixOpD* d_ops = nullptr; PixTap* d_taps = nullptr; int n_ops = 0; int act_floats = 0; };
+struct PProgram { PixOpD* d_ops = nullptr; PixTap* d_taps = nullptr; int n_ops = 0; int act_floats = 0; int ntaps = 0; };
 std::map<std::pair<const void*, long long>, PProgram> g_pprograms;
 
-size_t pix_lds_bytes(int act_floats) { return sizeof(float) * ((size_t)act_floats + P_ZERO_F + P_RED_F + P_STAT_SLOTS * 2 + P_SCR_F) + sizeof(int) * P_MAXTAP * P_TAP_I; }
+size_t pix_lds_bytes(int act_floats, int ntaps) { return sizeof(float) * ((size_t)act_floats + P_ZERO_F + P_RED_F + P_STAT_SLOTS * 2 + P_SCR_F) + sizeof(int) * (size_t)(ntaps + 1) * P_TAP_I; }
 
 const char* pixrun_build(const DevPlan& dp, int first, int count) {
   const Plan& plan = *dp.plan;
@@ -596,9 +602,9 @@ const char* pixrun_build(const DevPlan& dp, int first, int count) {
   b.preset = &packed; b.act_floats = b0.act_floats;
   if (const char* e = fill(b)) return e;
   if (b.stat_of.size() > (size_t)P_STAT_SLOTS) return "pixel kernel: too many statistics slots";
-  if (pix_lds_bytes(b.act_floats) > 160 * 1024) return "pixel kernel: the activations do not fit the LDS";
+  if (pix_lds_bytes(b.act_floats, (int)b.taps.size()) > 160 * 1024) return "pixel kernel: the activations do not fit the LDS";
   PProgram p;
-  p.n_ops = (int)b.ops.size(); p.act_floats = b.act_floats;
+  p.n_ops = (int)b.ops.size(); p.act_floats = b.act_floats; p.ntaps = (int)b.taps.size();
   if (hipMalloc(&p.d_taps, sizeof(PixTap) * (b.taps.size() + 1)) != hipSuccess) return "pixel kernel: hipMalloc failed";
   if (hipMemcpy(p.d_taps, b.taps.data(), sizeof(PixTap) * b.taps.size(), hipMemcpyHostToDevice) != hipSuccess) return "pixel kernel: hipMemcpy failed";
   for (PixOpD& d : b.ops) if (d.kind == OP_GEMM) d.taps = p.d_taps;
@@ -624,9 +630,9 @@ const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t s
   }
   const PProgram& p = it->second;
   const dim3 grid(plan.B), block(PNT);
-  const size_t ldsb = pix_lds_bytes(p.act_floats);
-  if (g_prof_start) hipExtLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, g_prof_start, g_prof_stop, 0, p.d_ops, p.n_ops, plan.B, p.act_floats, g_pix_dbg);
-  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p.d_ops, p.n_ops, plan.B, p.act_floats, g_pix_dbg);
+  const size_t ldsb = pix_lds_bytes(p.act_floats, p.ntaps);
+  if (g_prof_start) hipExtLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, g_prof_start, g_prof_stop, 0, p.d_ops, p.n_ops, plan.B, p.act_floats, p.d_taps, p.ntaps, g_pix_dbg);
+  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p.d_ops, p.n_ops, plan.B, p.act_floats, p.d_taps, p.ntaps, g_pix_dbg);
   return nullptr;
 }
 
