@@ -1162,7 +1162,8 @@ __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// y = GroupNorm(1,C)(u) * gamma + beta + x   -- one workgroup per sample
+// y = GroupNorm(1,C)(u) * gamma + beta + x   -- one workgroup per (sample, pixel slice); every slice repeats the (cheap) reduction of
+// the producer's partial sums in the same order, so the result does not depend on the slicing
 // ------------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void gn_res_kernel(const GnResArgs g) {
@@ -1181,7 +1182,7 @@ __global__ __launch_bounds__(256) void gn_res_kernel(const GnResArgs g) {
   __syncthreads();
   const float mean = s_mean, rstd = s_rstd;
   const int c4n = g.C / 4;
-  for (int idx = tid; idx < g.P * c4n; idx += 256) {
+  for (int idx = tid + 256 * blockIdx.y; idx < g.P * c4n; idx += 256 * gridDim.y) {
     const int p = idx / c4n, c = (idx - p * c4n) * 4;
     const long long row = (long long)p * g.B + b;
     const float4 u = *reinterpret_cast<const float4*>(g.u + row * g.ldu + c);
@@ -1653,7 +1654,11 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
     case OP_GN_RES: {
       const GnResOp& o = op.gr; GnResArgs g = make_gnres_args(o, prm, ws);
       if (o.out_ext) g.out = ext_out;
-      SBM_KLAUNCH(gn_res_kernel, dim3(o.B), dim3(256), 0, st, g);
+      // few samples: cut the pixels into slices so that about 512 workgroups run (B = 64: one workgroup per sample left 3/4 of the chip idle)
+      int slices = o.B >= 192 ? 1 : ceil_div(512, o.B);
+      const int sweeps = ceil_div(g.P * (g.C / 4), 256);
+      slices = slices > sweeps ? sweeps : slices; slices = slices > 16 ? 16 : (slices < 1 ? 1 : slices);
+      SBM_KLAUNCH(gn_res_kernel, dim3(o.B, slices), dim3(256), 0, st, g);
     } break;
     case OP_SINUS: {
       const SinusOp& o = op.si; const int n = o.B * o.ld;
