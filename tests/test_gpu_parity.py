@@ -378,8 +378,8 @@ def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
                 y = m(x, t)
             outs[pix] = y.clone()
             eng = m._engine_for(256, 8, 8)
-            st = (ctypes.c_uint * 300)()
-            pkg["lib"].check(pkg["lib"].lib().sbm_debug_chain_sync(eng.h, st, 300))
+            st = (ctypes.c_uint * 528)()                  # the whole ChainSync block: counters, arrival words, abort flag, barrier slots
+            pkg["lib"].check(pkg["lib"].lib().sbm_debug_chain_sync(eng.h, st, 528))
             assert not any(st), "chain synchronisation state must be clean between launches (no abort, counters reset)"
         finally:
             os.environ.pop("SBM_CHAIN_PIX", None)
