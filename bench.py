@@ -5,6 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+Started WITHOUT a launcher (`WORLD_SIZE` unset) and with `--gpus N > 1`, the script launches itself: the parent, before it makes
+any GPU call, starts N fresh child processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+127.0.0.1), relays rank 0's JSON line and exits with the worst child status.  `--dry` runs the same sharding / gather / timing
+plumbing on the CPU with `gloo` and a toy sample function (no GPU, no library): the launcher's own test.
+
 Workloads (BASELINE.json `configs`).  Default = config 2 (configs[1], and configs[2] when N > 1):
   2  PolyMNIST 5-modality unconditional sampling, 1000-step reverse SDE (VPSDE beta=(0.1,5), Euler-Maruyama predictor, pc=False),
      Unet(64, ch=5, (1,2,2,2)) over the (B,5,8,8) joint latent, then the five ResVAE decoders -> (B,3,32,32); batch 256 per GPU
@@ -219,6 +224,63 @@ def committed_profile(name):
     return j
 
 
+def self_launch(n, argv):
+    """`bench.py --gpus N` without a launcher: N child processes, one rank each.  The parent never touches the GPU (importing torch
+    does not initialise it), so no process that has initialised a GPU is ever replaced or forked."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc != 0]
+    if bad:
+        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
+    return max(abs(rc) for rc in rcs) if bad else 0
+
+
+def dry_run(args):
+    """The launcher / sharding / gather / max-over-ranks timing path with no GPU: gloo on the CPU, a toy sample function of the
+    GLOBAL row indices.  Rank 0 prints one JSON line whose n_gpus is the world size the process group actually has."""
+    from score_based_multimodal_autoencoder_amd import distributed as D
+    rank, world = D.init_from_env("gloo") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
+    B = 8
+
+    def sample_fn(first, count):
+        rows = torch.arange(first, first + count, dtype=torch.float32)
+        return rows[:, None] * torch.ones(1, 3), rows[:, None, None] * torch.ones(1, 2, 2) + 0.5
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+    for _ in range(args.warmup):
+        D.sample_sharded(sample_fn, world * B)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        a, b = D.sample_sharded(sample_fn, world * B)
+    barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    ok = bool(torch.equal(a[:, 0], torch.arange(world * B, dtype=torch.float32)) and torch.equal(b[:, 1, 1], torch.arange(world * B, dtype=torch.float32) + 0.5))
+    if rank == 0:
+        print(json.dumps({"dry": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gathered_rows": int(a.shape[0]), "rows_in_global_order": ok,
+                          "ms_per_step": 1e3 * float(tmax.item()) / max(args.steps, 1), "scaling": "weak"}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,7 +290,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--dry", action="store_true", help="CPU / gloo rehearsal of the launcher and the sharded path (no GPU)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))       # BEFORE any GPU call of this process
+    if args.dry:
+        sys.exit(dry_run(args))
     cfg = args.config
     W = WORK[cfg]
     B = W["B"]
@@ -237,7 +304,7 @@ def main():
     from score_based_multimodal_autoencoder_amd.sde_helper2 import VPSDE
     rank, world = D.init_from_env("nccl") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
     if world != args.gpus and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+        print(f"warning: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}; the line reports n_gpus = {world}", file=sys.stderr)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)

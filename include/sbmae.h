@@ -13,7 +13,9 @@
  * of the model handle (ordered after the caller's stream at entry and before it at exit by events) and synchronise that stream
  * when they replay a captured hipGraph (use_graph, n_run > 1: the graph is released before returning) or when elapsed_ms is
  * requested.  A chain-kernel barrier that timed out in an earlier call (not every workgroup resident) is reported by the next
- * sbm_model_forward / sbm_sampler_run on the same handle, without a synchronisation, through a host-mapped flag.
+ * sbm_model_forward / sbm_sampler_run / sbm_model_check on the same handle (and by sbm_model_destroy), through a host-mapped flag:
+ * until then the calls in between return 0 with invalid results -- call sbm_model_check(m, 1, stream) before trusting an output
+ * that no later call on the handle will vouch for.
  * Every function returns 0 on success and a non-zero code on failure; sbm_last_error() then
  * returns a message (thread-local).  No C++ exception crosses this boundary.  A model handle is not
  * thread-safe; use one handle per device and per batch size.
@@ -73,7 +75,20 @@ long sbm_spec(int kind, const int* cfg, int index, char* name, int name_capacity
  * reference decodes the strided slice z_out[:, ind].view(B, size_z), train_poly_unet_cont.py:303). */
 int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const float* const* host_tensors,
                      int n_tensors, sbm_model** out);
-void sbm_model_destroy(sbm_model* m);
+/* Releases the handle.  Waits for the whole device first (hipDeviceSynchronize): forwards and step kernels are enqueued
+ * asynchronously on the caller's streams, and a handle dropped right behind such a call must not free the arenas under them.
+ * Returns non-zero (message in sbm_last_error) when a HIP call of the tear-down failed, or when a chain-kernel barrier time-out
+ * was still unreported on this handle: then every result produced on it since its last successful check is invalid.
+ * The handle is gone in every case.  Replaces `del model` / interpreter exit of the reference. */
+int sbm_model_destroy(sbm_model* m);
+
+/* Chain-kernel health of a handle (models whose low-resolution levels run in the XCD-resident chain kernel; always 0 for the
+ * others): non-zero when one of its barriers has timed out since the last successful check -- ALL results produced on the handle
+ * since then are invalid (once a launch has aborted, every later launch returns at once until the state is reset, which this call
+ * does).  `sync` != 0 first waits for `stream` and for the model's private stream, so the answer covers all work enqueued so far;
+ * with sync == 0 the call only reads a host-mapped word.  sbm_model_forward / sbm_sampler_run make the same (unsynchronised) check
+ * at entry, sbm_sampler_run also at exit whenever it synchronised anyway (use_graph or elapsed_ms). */
+int sbm_model_check(sbm_model* m, int sync, void* stream);
 
 /* info[0..7] = n_ops, workspace bytes, parameter bytes, dense FLOP per call, executed FLOP per call,
  *              n seg_gemm launches, batch, dense FLOP per call computed by seg_gemm launches */

@@ -18,7 +18,7 @@ SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA, SBM_MLP, SBM_RESENC, SBM_ATTRENC
 OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "nchw_to_pbc", "bilinear", "gn_final", "gn32",
                  "attn_qkv", "chain_kernel", "avgpool", "rowrun_kernel"]
 
-EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy",
+EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy", "sbm_model_check",
            "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step", "sbm_langevin_norms", "sbm_langevin_update", "sbm_clg_forward", "sbm_clg_guide",
            "sbm_fill_normal", "sbm_sampler_run", "sbm_cond_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_ctl", "sbm_debug_chain_stamps", "sbm_debug_row_stamps", "sbm_debug_pix_stamps",
@@ -90,7 +90,7 @@ def lib():
         L.sbm_spec.argtypes = [i, ip, i, ctypes.c_char_p, i]
         L.sbm_model_create.argtypes = [i, ip, i, i, ctypes.POINTER(vp), i, ctypes.POINTER(vp)]
         L.sbm_model_destroy.argtypes = [vp]
-        L.sbm_model_destroy.restype = None
+        L.sbm_model_check.argtypes = [vp, i, vp]
         L.sbm_model_info.argtypes = [vp, ctypes.POINTER(dbl)]
         L.sbm_model_forward.argtypes = [vp, vp, vp, vp, vp]
         L.sbm_model_forward_aux.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -245,13 +245,20 @@ class Engine:
         check(lib().sbm_model_gemm_flops(self.h, v))
         return (v[0] - v[2], v[1] - v[3], v[4]) if sampler_mix else (v[0], v[1], v[4])
 
+    def check(self, sync=True):
+        """Raise if a chain-kernel barrier timed out on this handle since the last check (then ALL results produced on it since are
+        invalid).  sync=True first waits for the current stream and the model's own, so the answer covers everything enqueued."""
+        check(lib().sbm_model_check(self.h, int(bool(sync)), stream_ptr()))
+
     def close(self):
+        """Destroy the handle (waits for the device).  Raises if the tear-down failed or an unreported chain time-out was pending."""
         if getattr(self, "h", None):
-            lib().sbm_model_destroy(self.h)
-            self.h = None
+            h, self.h = self.h, None
+            check(lib().sbm_model_destroy(h))
 
     def __del__(self):
         try:
             self.close()
-        except Exception:
-            pass
+        except Exception as e:                      # an exception cannot leave a finaliser: say it where it can be seen
+            import sys
+            print(f"sbmae: error while releasing a model handle: {e}", file=sys.stderr)

@@ -101,13 +101,14 @@ static int chain_prior_abort(sbm_model* m, hipStream_t st, const char* who) {
   (void)hipMemsetAsync(m->d_chain_sync, 0, sizeof(ChainSync), st);
   __atomic_store_n(m->h_abort, 0u, __ATOMIC_RELAXED);
   return fail(std::string(who) + ": a chain-kernel barrier timed out in an earlier call on this model (not every workgroup was resident?); "
-              "the results of that call are invalid.  The synchronisation state has been reset; repeat the call.");
+              "all results produced on the handle since the last successful check are invalid.  The synchronisation state has been reset; "
+              "repeat the calls.");
 }
 
 extern "C" {
 
 const char* sbm_last_error(void) { return g_err.c_str(); }
-int sbm_abi_version(void) { return 2; }
+int sbm_abi_version(void) { return 3; }
 
 int sbm_spec_count(int kind, const int* cfg) { return (int)specs_of(kind, cfg).size(); }
 
@@ -118,31 +119,68 @@ long sbm_spec(int kind, const int* cfg, int index, char* name, int cap) {
   return (long)s[index].numel();
 }
 
-void sbm_model_destroy(sbm_model* m) {
-  if (!m) return;
-  // forwards run asynchronously on the CALLER's streams: nothing of this model (workspace, weights, the host-mapped abort word the
-  // chain kernel may still write) may be released under a kernel in flight
-  (void)hipDeviceSynchronize();
+// Release a handle.  Work of this model may still be in flight: sbm_model_forward and the single-kernel entry points enqueue on the
+// CALLER's stream and return at once, so a handle dropped right behind such a call (a temporary module going out of scope in
+// Python) is destroyed under running kernels that read the weights / workspace arenas freed here.  Destroy therefore waits for the
+// whole device first.  (Round 2 recorded what happens without that wait -- gpurun_out/t7_r2.log, DESIGN.md section 1 "Streams".)
+// Every HIP status is kept: the first failures are joined into sbm_last_error and the call returns non-zero; a chain-kernel barrier
+// time-out that no later call on the handle has reported yet is reported here.
+int sbm_model_destroy(sbm_model* m) {
+  if (!m) return 0;
+  std::string errs;
+  auto note = [&](const char* what, hipError_t e) {
+    if (e == hipSuccess) return;
+    if (!errs.empty()) errs += "; ";
+    errs += what; errs += ": "; errs += hipGetErrorString(e);
+  };
+  static const bool debug_nosync = std::getenv("SBM_DEBUG_DESTROY_NOSYNC") != nullptr;   // tools/destroy_repro.py only: reproduces the round-2 abort
+  if (!debug_nosync) note("hipDeviceSynchronize", hipDeviceSynchronize());
+  const bool aborted = m->h_abort && __atomic_load_n(m->h_abort, __ATOMIC_RELAXED) != 0u;
   rowrun_release(&m->plan);
   pixrun_release(&m->plan);
-  if (m->own) (void)hipStreamSynchronize(m->own);
-  if (m->d_params) (void)hipFree(m->d_params);
-  if (m->d_ws) (void)hipFree(m->d_ws);
-  if (m->d_cold) (void)hipFree(m->d_cold);
-  if (m->d_chain_ops) (void)hipFree(m->d_chain_ops);
-  if (m->d_chain_sync) (void)hipFree(m->d_chain_sync);
-  if (m->d_chain_sched) (void)hipFree(m->d_chain_sched);
-  if (m->h_abort) (void)hipHostFree(m->h_abort);
-  if (m->d_score) (void)hipFree(m->d_score);
-  if (m->d_norms) (void)hipFree(m->d_norms);
-  if (m->d_counter) (void)hipFree(m->d_counter);
-  if (m->d_time_table) (void)hipFree(m->d_time_table);
-  if (m->ev_in) (void)hipEventDestroy(m->ev_in);
-  if (m->ev_out) (void)hipEventDestroy(m->ev_out);
-  if (m->ev_t0) (void)hipEventDestroy(m->ev_t0);
-  if (m->ev_t1) (void)hipEventDestroy(m->ev_t1);
-  if (m->own) (void)hipStreamDestroy(m->own);
+  if (m->own) note("hipStreamSynchronize(model stream)", hipStreamSynchronize(m->own));
+  if (m->d_params) note("hipFree(params)", hipFree(m->d_params));
+  if (m->d_ws) note("hipFree(workspace)", hipFree(m->d_ws));
+  if (m->d_cold) note("hipFree(cold args)", hipFree(m->d_cold));
+  if (m->d_chain_ops) note("hipFree(chain ops)", hipFree(m->d_chain_ops));
+  if (m->d_chain_sync) note("hipFree(chain sync)", hipFree(m->d_chain_sync));
+  if (m->d_chain_sched) note("hipFree(chain schedule)", hipFree(m->d_chain_sched));
+  if (m->h_abort) note("hipHostFree(abort word)", hipHostFree(m->h_abort));
+  if (m->d_score) note("hipFree(score)", hipFree(m->d_score));
+  if (m->d_norms) note("hipFree(norms)", hipFree(m->d_norms));
+  if (m->d_counter) note("hipFree(step control)", hipFree(m->d_counter));
+  if (m->d_time_table) note("hipFree(time table)", hipFree(m->d_time_table));
+  if (m->ev_in) note("hipEventDestroy", hipEventDestroy(m->ev_in));
+  if (m->ev_out) note("hipEventDestroy", hipEventDestroy(m->ev_out));
+  if (m->ev_t0) note("hipEventDestroy", hipEventDestroy(m->ev_t0));
+  if (m->ev_t1) note("hipEventDestroy", hipEventDestroy(m->ev_t1));
+  if (m->own) note("hipStreamDestroy", hipStreamDestroy(m->own));
   delete m;
+  if (aborted) {
+    std::string msg = "sbm_model_destroy: a chain-kernel barrier timed out on this model and no call reported it: every result produced on "
+                      "the handle since its last successful sbm_model_check / forward / sampler call is invalid";
+    if (!errs.empty()) msg += " (also: " + errs + ")";
+    return fail(msg);
+  }
+  if (!errs.empty()) return fail("sbm_model_destroy: " + errs);
+  return 0;
+}
+
+// Has a chain-kernel barrier timed out since the last check?  Reads the host-mapped word; `sync` != 0 waits for the model's private
+// stream and for `stream` first, so that the answer covers everything enqueued so far.  On a time-out the synchronisation state is
+// reset and the call fails: ALL results produced on this handle since the last successful check are invalid (an aborted launch
+// makes every later launch return at once until the state is reset).
+int sbm_model_check(sbm_model* m, int sync, void* stream) {
+  if (!m) return fail("sbm_model_check: bad arguments");
+  if (sync) {
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (m->own) HIPCHK(hipStreamSynchronize(m->own));
+  }
+  if (!m->h_abort || !__atomic_load_n(m->h_abort, __ATOMIC_RELAXED)) return 0;
+  (void)hipMemsetAsync(m->d_chain_sync, 0, sizeof(ChainSync), (hipStream_t)stream);
+  __atomic_store_n(m->h_abort, 0u, __ATOMIC_RELAXED);
+  return fail("sbm_model_check: a chain-kernel barrier timed out on this model (not every workgroup was resident?): all results produced on "
+              "the handle since the last successful check are invalid.  The synchronisation state has been reset; repeat the calls.");
 }
 
 int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const float* const* host_tensors, int n_tensors, sbm_model** out) {

@@ -57,7 +57,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/sbmae.h but not exported"
     assert set(_lib.EXPORTS) <= set(declared)
-    assert L.sbm_abi_version() == 2
+    assert L.sbm_abi_version() == 3
     # the spec tables are host-only: usable without a GPU, and identical to the Python arch tables
     cfg = _lib.unet_cfg_ints(64, 5, (1, 2, 2, 2), 8, 8)
     assert _lib.specs(_lib.SBM_UNET, cfg) == [(k, int(np.prod(s))) for k, s in arch.unet_entries(dim=64, channels=5, dim_mults=(1, 2, 2, 2))]
@@ -224,3 +224,21 @@ def test_two_rank_sharding_over_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o}"
         assert f"rank {r} ok" in o
+
+
+def test_bench_launches_its_own_ranks_when_no_launcher_is_present():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start two ranks itself (fresh child processes, before
+    any GPU call of the parent) and report the world size the process group really has.  --dry runs the launcher, the sharded path
+    (distributed.sample_sharded), the single all-gather and the max-over-ranks timing on the CPU with gloo."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                       # ONE JSON line, from rank 0
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["gathered_rows"] == 16 and j["rows_in_global_order"] and j["steps"] == 2
+    # with a launcher's environment the script must NOT spawn again: one process, world size from the environment
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry"], env=env, capture_output=True, text=True, timeout=300)
+    assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1
