@@ -24,6 +24,7 @@ z_cond) are resident in HBM before the timed region; the in-loop noise is drawn 
 import argparse
 import hashlib
 import json
+import math
 import os
 import statistics
 import sys
@@ -209,6 +210,46 @@ def cpu_baseline(cfg, reps=3, n_steps=20):
     return out
 
 
+def extra_measurements(cfg, score, decs, sde, x0, zc, device):
+    """The rest of the path's surface, timed with the sampler's own event timing or wall clock around a synchronised region (VERDICT r2
+    item 6; SURVEY 8(d): "with and without the corrector").  Config 2 only carries the PolyMNIST-specific entries."""
+    from score_based_multimodal_autoencoder_amd import langevin as LG
+    from score_based_multimodal_autoencoder_amd.sde_helper2 import cond_sampler, uncond_sampler
+    W = WORK[cfg]
+    B = x0.shape[0]
+    shape = (B, W["n_mod"], W["hw"], W["hw"])
+    kw = {} if zc is None else {"z_cond": zc}
+    out = {}
+
+    def wall(fn, reps=1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, r
+
+    # predictor-corrector sampling (sde_helper2.py:124-126): two score evaluations per step
+    _, ms = uncond_sampler(shape, score, device, sde, x0=x0, seed=11, pc=True, return_timing=True, **kw)
+    out["pc_true"] = {"ms_per_sde_step": ms / N_SDE, "samples_per_s_loop_only": B / (ms * 1e-3), "note": "corrector (n_steps=1, snr=0.16) + predictor, fused device loop"}
+    # conditional loop (train_poly_unet_cont.py:340-381 / train_lat_celebhq_unet_cont2.py:286-316): modality 0 observed, re-noised every step
+    z_obs = x0.clone()
+    try:
+        t, _ = wall(lambda: cond_sampler(z_obs, [0], score, sde, noise_obs=True, seed=12, **kw))
+        out["cond_sampler_fused"] = {"ms_per_sde_step": 1e3 * t / N_SDE, "note": "observed modality re-noised in front of every step, one captured graph"}
+    except Exception as exc:                      # a signature this build does not offer must not cost the headline line
+        out["cond_sampler_fused"] = {"error": str(exc)[:200]}
+    if cfg == 2:
+        try:
+            sig = torch.exp(torch.linspace(math.log(1.0), math.log(0.01), 10))
+            n_calls = 10 * 20
+            t, _ = wall(lambda: LG.annealed_langevin(score, x0.reshape(B, W["n_mod"], -1), sig, iter_num=20, seed=13, hw=(W["hw"], W["hw"])))
+            out["annealed_langevin"] = {"score_calls_per_s": n_calls / t, "ms_per_score_call": 1e3 * t / n_calls, "note": "fid_upd10.gen_ae shape: 10 sigma levels x 20 steps, Python loop over fused step kernels"}
+        except Exception as exc:
+            out["annealed_langevin"] = {"error": str(exc)[:200]}
+    return out
+
+
 def committed_profile(name):
     """A committed rocprofv3 summary of THIS build (profiles/<name>), or None when its recorded library hash is not the hash of the
     library this run loaded (the kernels changed since it was taken: the number would be stale)."""
@@ -291,6 +332,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--dry", action="store_true", help="CPU / gloo rehearsal of the launcher and the sharded path (no GPU)")
+    ap.add_argument("--extra", action="store_true", help="also time the rest of the surface (corrector on, conditional loops, annealed Langevin): an `extra` block")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus, sys.argv[1:]))       # BEFORE any GPU call of this process
@@ -380,10 +422,13 @@ def main():
         prof = eng.profile(xs, tt, so, reps=20 if cfg == 2 else 5, sampler_mix=True)      # the launches one SDE step of the timed loop makes
         log("per-kernel profile done")
         f_seg, f_chain, f_row = eng.gemm_flops(sampler_mix=True)
+        uses_pix = bool(eng.info.get("uses_pix"))
         kern = {}
         for name, label, fl in (("seg_gemm", "seg_gemm<BM,BN> (fp32 MFMA implicit-GEMM conv, one launch per layer)", f_seg),
-                                ("chain_kernel", "chain_kernel (XCD-resident run of the 4x4 and 2x2 layers: fp32 MFMA GEMMs + dwconv/attention/GroupNorm glue)", f_chain),
-                                ("rowrun_kernel", "rowrun_kernel (the 1x1 level: four samples per workgroup, LDS-resident, v_mfma_f32_4x4x1 weight streaming)", f_row)):
+                                ("pixrun_kernel", "pixrun_kernel (the 4x4, 2x2 and 1x1 levels as ONE launch of sample-owned workgroups: activations in LDS, weights streamed "
+                                                  "from L2 in MFMA fragment order through an AGPR ring; fp32 MFMA 16x16x4 / 4x4x1 + dwconv/attention/GroupNorm glue)", f_chain if uses_pix else 0.0),
+                                ("chain_kernel", "chain_kernel (legacy: XCD-resident run of the 4x4 and 2x2 layers)", 0.0 if uses_pix else f_chain),
+                                ("rowrun_kernel", "rowrun_kernel (legacy: the 1x1 level, four samples per workgroup)", f_row)):
             k = prof.get(name, dict(ms=0.0, launches=0))
             if k["launches"] and fl > 0:
                 kern[name] = dict(kernel=label, launches_per_forward=k["launches"], avg_launch_us=1e3 * k["ms"] / k["launches"], ms_per_forward=k["ms"],
@@ -393,7 +438,7 @@ def main():
         # (separate FETCH_SIZE / WRITE_SIZE / SQ passes over eager forwards, tools/traffic_probe.py; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950; unit KB).  Null when the profile was taken with a different build.
         traffic = mfma_busy = None
-        tag = f"r02_c{cfg}"
+        tag = f"r03_c{cfg}"
         tj = committed_profile(f"{tag}_traffic.json")
         if tj:
             rows = [v for k, v in tj["kernels"].items() if dom in k]
@@ -424,6 +469,17 @@ def main():
             "per_kernel_ms": {k: round(v["ms"], 4) for k, v in prof.items() if v["launches"]},
             "lib_hash": lib_hash(),
         }
+        if uses_pix and "pixrun_kernel" in kern:
+            # the sample-owned kernel is bounded by two things at once: the matrix pipe on the 4x4 level and the L2 -> CU weight stream on
+            # the 2x2 / 1x1 levels (every workgroup reads every weight byte once per launch)
+            mb = eng.info["pix_fragment_mb"]
+            line["roofline"]["pixrun_weight_stream"] = {
+                "fragment_mb_per_workgroup": mb, "workgroups": B,
+                "l2_to_cu_GBps_per_workgroup": mb * 1e6 / (kern["pixrun_kernel"]["ms_per_forward"] * 1e-3) / 1e9,
+                "l2_aggregate_TBps": B * mb * 1e6 / (kern["pixrun_kernel"]["ms_per_forward"] * 1e-3) / 1e12,
+                "note": "measured ceiling of this access pattern (tools/pixgemm_probe.hip, memory-only): 118 GB/s per workgroup, 30 TB/s aggregate"}
+        if world == 1 and args.extra:
+            line["extra"] = extra_measurements(cfg, score, decs, sde, x0, zc, device)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_reps, args.cpu_steps)
         print(json.dumps(line), flush=True)

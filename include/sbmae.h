@@ -90,9 +90,13 @@ int sbm_model_destroy(sbm_model* m);
  * at entry, sbm_sampler_run also at exit whenever it synchronised anyway (use_graph or elapsed_ms). */
 int sbm_model_check(sbm_model* m, int sync, void* stream);
 
-/* info[0..7] = n_ops, workspace bytes, parameter bytes, dense FLOP per call, executed FLOP per call,
- *              n seg_gemm launches, batch, dense FLOP per call computed by seg_gemm launches */
+/* info[0..9] = n_ops, workspace bytes, parameter bytes, dense FLOP per call, executed FLOP per call,
+ *              n seg_gemm launches, batch, dense FLOP per call computed by seg_gemm launches,
+ *              1 if the low-resolution levels run in the sample-owned pixel kernel (pixrun.hip), MB of its fragment-order weights */
 int sbm_model_info(const sbm_model* m, double* info);
+/* Why the low-resolution levels of this Unet do not run in the sample-owned pixel kernel (NUL-terminated; empty when they do): the
+ * choice between that kernel and the legacy per-layer / chain kernels is made once in sbm_model_create and reported here. */
+int sbm_model_note(const sbm_model* m, char* buf, int capacity);
 
 /* One forward pass.
  *   SBM_UNET:    in = x (B,C,H,W), t = time (B,), out = score (B,C,H,W)        == Unet.forward(x, time), unet_model.py:275

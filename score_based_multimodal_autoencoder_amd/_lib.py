@@ -16,10 +16,10 @@ HEADERS = ["plan.h", "device.h", os.path.join("..", "..", "include", "sbmae.h")]
 
 SBM_UNET, SBM_RESDEC, SBM_ATTRDEC, SBM_UNET_OA, SBM_MLP, SBM_RESENC, SBM_ATTRENC, SBM_CLG = 0, 1, 2, 3, 4, 5, 6, 7
 OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "nchw_to_pbc", "bilinear", "gn_final", "gn32",
-                 "attn_qkv", "chain_kernel", "avgpool", "rowrun_kernel"]
+                 "attn_qkv", "chain_kernel", "avgpool", "rowrun_kernel", "pixrun_kernel"]
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy", "sbm_model_check",
-           "sbm_model_info", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step", "sbm_langevin_norms", "sbm_langevin_update", "sbm_clg_forward", "sbm_clg_guide",
+           "sbm_model_info", "sbm_model_note", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step", "sbm_langevin_norms", "sbm_langevin_update", "sbm_clg_forward", "sbm_clg_guide",
            "sbm_fill_normal", "sbm_sampler_run", "sbm_cond_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_ctl", "sbm_debug_chain_stamps", "sbm_debug_row_stamps", "sbm_debug_pix_stamps",
            "sbm_ddpm_step", "sbm_fid_accumulate", "sbm_fid_finalize_stats", "sbm_fid_work_doubles", "sbm_fid_frechet", "sbm_debug_dgemm_tn"]
@@ -92,6 +92,7 @@ def lib():
         L.sbm_model_destroy.argtypes = [vp]
         L.sbm_model_check.argtypes = [vp, i, vp]
         L.sbm_model_info.argtypes = [vp, ctypes.POINTER(dbl)]
+        L.sbm_model_note.argtypes = [vp, ctypes.c_char_p, i]
         L.sbm_model_forward.argtypes = [vp, vp, vp, vp, vp]
         L.sbm_model_forward_aux.argtypes = [vp, vp, vp, vp, vp, vp]
         L.sbm_model_set_aux.argtypes = [vp, vp]
@@ -214,10 +215,13 @@ class Engine:
         h = ctypes.c_void_p()
         check(L.sbm_model_create(kind, ints(cfg), batch, in_pitch, ptrs, len(sp), ctypes.byref(h)))
         self.h = h
-        info = (ctypes.c_double * 8)()
+        info = (ctypes.c_double * 10)()
         check(L.sbm_model_info(self.h, info))
         self.info = dict(n_ops=int(info[0]), workspace_bytes=int(info[1]), flops_dense=info[3], flops_exec=info[4], flops_dense_gemm=info[7],
-                         n_gemm=int(info[5]))
+                         n_gemm=int(info[5]), uses_pix=bool(info[8]), pix_fragment_mb=info[9])
+        note = ctypes.create_string_buffer(512)
+        check(L.sbm_model_note(self.h, note, 512))
+        self.info["pix_note"] = note.value.decode(errors="replace")
 
     def forward(self, x, t, out):
         check(lib().sbm_model_forward(self.h, x.data_ptr(), t.data_ptr() if t is not None else None, out.data_ptr(),
@@ -260,5 +264,8 @@ class Engine:
         try:
             self.close()
         except Exception as e:                      # an exception cannot leave a finaliser: say it where it can be seen
-            import sys
-            print(f"sbmae: error while releasing a model handle: {e}", file=sys.stderr)
+            try:
+                import sys
+                print(f"sbmae: error while releasing a model handle: {e}", file=sys.stderr)
+            except Exception:                       # interpreter shutdown: nothing left to print with
+                pass

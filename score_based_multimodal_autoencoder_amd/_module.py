@@ -83,10 +83,19 @@ def as_f32_cuda(t, what):
     return t.contiguous()
 
 
-def fresh_seed(seed=None):
+def fresh_seed(seed=None, group=None):
     """Philox key of one sampler call.  `None` draws a fresh 64-bit key from torch's default generator, so successive calls get
     independent in-loop noise (as the reference's per-call `torch.randn_like`, sde_helper2.py:47,96), `torch.manual_seed`
-    reproduces a run, and the generator state advances."""
-    if seed is None:
-        return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
-    return int(seed) & 0xFFFFFFFFFFFFFFFF
+    reproduces a run, and the generator state advances.  Under an initialised process group the ranks must share ONE key -- the noise
+    is a single global stream indexed by the global sample number -- so rank 0's draw is broadcast (every rank still
+    draws, keeping the generators in step); an explicit `seed=` is taken as is and must be the same on every rank."""
+    if seed is not None:
+        return int(seed) & 0xFFFFFFFFFFFFFFFF
+    key = torch.empty((), dtype=torch.int64).random_()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        k = key.reshape(1).to(dev)
+        dist.broadcast(k, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        key = k.cpu()[0]
+    return int(key.item()) & 0xFFFFFFFFFFFFFFFF

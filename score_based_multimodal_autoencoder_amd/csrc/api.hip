@@ -38,6 +38,8 @@ struct sbm_model {
   unsigned* h_abort = nullptr;    // host-mapped word the chain kernel raises when a barrier times out (polled without synchronising)
   const float* aux_persistent = nullptr;   // z_cond used by sbm_sampler_run (sbm_model_set_aux)
   DevPlan dp;
+  double pix_frag_mb = 0.0;       // fragment-order weight copies of the pixel kernel (MB), 0 when it is not in use
+  std::string pix_reason;         // why a Unet does not use the pixel kernel (empty when it does)
   // sampler scratch (score nets only)
   float* d_score = nullptr;
   float* d_norms = nullptr;
@@ -137,7 +139,7 @@ int sbm_model_destroy(sbm_model* m) {
   if (!debug_nosync) note("hipDeviceSynchronize", hipDeviceSynchronize());
   const bool aborted = m->h_abort && __atomic_load_n(m->h_abort, __ATOMIC_RELAXED) != 0u;
   rowrun_release(&m->plan);
-  pixrun_release(&m->plan);
+  pixrun_release(m->dp);
   if (m->own) note("hipStreamSynchronize(model stream)", hipStreamSynchronize(m->own));
   if (m->d_params) note("hipFree(params)", hipFree(m->d_params));
   if (m->d_ws) note("hipFree(workspace)", hipFree(m->d_ws));
@@ -183,7 +185,27 @@ int sbm_model_check(sbm_model* m, int sync, void* stream) {
               "the handle since the last successful check are invalid.  The synchronisation state has been reset; repeat the calls.");
 }
 
+static int model_create_impl(int kind, const int* cfg, int batch, int in_pitch, const float* const* host_tensors, int n_tensors, sbm_model** out, bool pix_mode, std::string* pix_reason);
+
+// The low-resolution levels of a Unet (4x4 and smaller) run as sample-owned workgroups (pixrun.hip) whenever that kernel can take them
+// (op shapes, LDS, weight volume: decided HERE, once, never at launch time); otherwise -- or with SBM_PIX=0 -- the model is planned
+// again the legacy way (XCD-resident chain kernel for large batches + row kernel, per-layer launches for small ones).  The reason
+// is kept on the handle (sbm_model_info) and printed with SBM_PIX_VERBOSE.
 int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const float* const* host_tensors, int n_tensors, sbm_model** out) {
+  const char* pe = std::getenv("SBM_PIX");
+  const bool try_pix = kind == SBM_UNET && !(pe && std::atoi(pe) == 0);
+  std::string reason = try_pix ? "" : (kind == SBM_UNET ? "disabled by SBM_PIX=0" : "");
+  if (try_pix) {
+    const int rc = model_create_impl(kind, cfg, batch, in_pitch, host_tensors, n_tensors, out, true, &reason);
+    if (rc == 0 || reason.empty()) return rc;          // built, or failed for a reason that has nothing to do with the pixel kernel
+    if (std::getenv("SBM_PIX_VERBOSE")) fprintf(stderr, "sbmae: low-resolution levels stay with the legacy kernels: %s\n", reason.c_str());
+  }
+  const int rc = model_create_impl(kind, cfg, batch, in_pitch, host_tensors, n_tensors, out, false, nullptr);
+  if (rc == 0 && *out) (*out)->pix_reason = reason;
+  return rc;
+}
+
+static int model_create_impl(int kind, const int* cfg, int batch, int in_pitch, const float* const* host_tensors, int n_tensors, sbm_model** out, bool pix_mode, std::string* pix_reason) {
   if (!cfg || !host_tensors || !out || batch <= 0) return fail("sbm_model_create: bad arguments");
   *out = nullptr;
   int ndev = 0;
@@ -204,6 +226,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
     return 0;
   }
   bool ok = false;
+  plan_set_pix_mode(pix_mode ? 1 : 0);
   if (kind == SBM_UNET) ok = build_unet_plan(unet_cfg_from_ints(cfg), batch, host_tensors, &m->plan);
   else if (kind == SBM_RESDEC) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), batch, in_pitch, host_tensors, &m->plan);
   else if (kind == SBM_ATTRDEC) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, batch, in_pitch, host_tensors, &m->plan); }
@@ -212,6 +235,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   else if (kind == SBM_RESENC) ok = build_resenc_plan(resdec_cfg_from_ints(cfg), batch, host_tensors, &m->plan);
   else if (kind == SBM_ATTRENC) { AttrEncCfg c; c.size_z = cfg[0]; c.att_size = cfg[1]; c.ae = cfg[2]; ok = build_attrenc_plan(c, batch, host_tensors, &m->plan); }
   else m->plan.error = "unknown model kind";
+  plan_set_pix_mode(0);
   if (!ok) { std::string e = m->plan.error; delete m; return fail("sbm_model_create: " + e); }
   const size_t pbytes = m->plan.params.size() * sizeof(float), wbytes = (size_t)m->plan.ws_floats * sizeof(float);
   hipError_t e;
@@ -219,7 +243,8 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
   if ((e = hipMalloc(&m->d_ws, wbytes ? wbytes : 16)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(workspace)", e); }
   if ((e = hipMemcpy(m->d_params, m->plan.params.data(), pbytes, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(params)", e); }
   if ((e = hipMemset(m->d_ws, 0, wbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemset(workspace)", e); }
-  std::vector<float>().swap(m->plan.params);          // host copy no longer needed
+  std::vector<float> host_params;
+  host_params.swap(m->plan.params);                   // the plan no longer needs its host copy; the pixel kernel's packer (below) still does
   for (int i = 0; i + 1 < (int)m->plan.ops.size(); ++i) if (qkv_linattn_fusable(m->plan, i)) m->plan.ops[i].fuse_next = 1;
   if (kind == SBM_UNET || kind == SBM_UNET_OA) {
     if ((e = hipMalloc(&m->d_counter, 64)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(counter)", e); }
@@ -240,7 +265,14 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
     if ((e = hipMemcpy(m->d_cold, cold.data(), sizeof(GemmCold) * nops, hipMemcpyHostToDevice)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemcpy(cold args)", e); }
     // programs of the row kernel (rowrun.hip).  A level too wide for the LDS (activations of four samples) stays in the chain kernel:
     // same descriptors, same numerics class, decided here once -- never at launch time.
-    if (const char* re = rowrun_prepare(m->dp)) {
+    if (pix_mode) {
+      // sample-owned kernel: fragment-order copies of the low-resolution weights + the programs of its runs.  A "pixel kernel: ..." failure
+      // sends the caller back to the legacy plan.
+      if (const char* pe = pixrun_prepare(m->dp, host_params.data(), &m->pix_frag_mb)) { if (pix_reason) *pix_reason = pe; std::string msg = pe; sbm_model_destroy(m); return fail("sbm_model_create: " + msg); }
+      m->dp.use_pix = true;
+    }
+    std::vector<float>().swap(host_params);
+    if (const char* re = pix_mode ? nullptr : rowrun_prepare(m->dp)) {
       if (std::string(re).find("do not fit") == std::string::npos) { std::string msg = re; sbm_model_destroy(m); return fail("sbm_model_create: " + msg); }
       rowrun_release(&m->plan);
       for (Op& op : m->plan.ops) if (op.row) { op.row = 0; op.chain = 1; }
@@ -252,7 +284,7 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
     for (size_t i = 0; i < nops; ++i) {
       const Op& op = m->plan.ops[i];
       std::memset(&cops[i], 0, sizeof(ChainOp));
-      if (!op.chain) continue;
+      if (!op.chain || pix_mode) continue;              // pixel mode: the marked ops never run in the chain kernel
       any_chain = true;
       cops[i].kind = op.kind;
       if (op.kind == OP_GEMM) {
@@ -309,13 +341,6 @@ int sbm_model_create(int kind, const int* cfg, int batch, int in_pitch, const fl
       unsigned* dev_view = nullptr;
       if ((e = hipHostGetDevicePointer(reinterpret_cast<void**>(&dev_view), m->h_abort, 0)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipHostGetDevicePointer", e); }
       m->dp.chain_ctl.abort_host = dev_view;
-      // SBM_PIX=1 (opt-in, experimental): the same ops as sample-owned workgroups (pixrun.hip).  Programs are built here; anything the
-      // pixel kernel cannot take (shapes, LDS) leaves ALL of them to the chain kernel -- decided once, never at launch time.
-      if (std::getenv("SBM_PIX")) {
-        const char* pe = pixrun_prepare(m->dp);
-        if (pe) { pixrun_release(&m->plan); if (std::getenv("SBM_PIX_VERBOSE")) fprintf(stderr, "sbmae: chain-level ops stay in the chain kernel: %s\n", pe); }
-        else m->dp.use_pix = true;
-      }
     }
   }
   if (kind == SBM_UNET || kind == SBM_UNET_OA) {
@@ -336,6 +361,15 @@ int sbm_model_info(const sbm_model* m, double* info) {
   int ng = 0; for (auto& op : m->plan.ops) ng += op.kind == OP_GEMM;
   info[0] = (double)m->plan.ops.size(); info[1] = (double)m->plan.ws_floats * 4; info[2] = 0;
   info[3] = m->plan.flops_dense; info[4] = m->plan.flops_exec; info[5] = ng; info[6] = m->plan.B; info[7] = m->plan.flops_dense_gemm;
+  info[8] = m->dp.use_pix ? 1.0 : 0.0; info[9] = m->pix_frag_mb;
+  return 0;
+}
+
+// Why a Unet's low-resolution levels do NOT run in the sample-owned pixel kernel (empty string: they do, or the model is not a Unet).
+// The choice is made once, in sbm_model_create, and kept here: never silent, never at launch time.
+int sbm_model_note(const sbm_model* m, char* buf, int cap) {
+  if (!m || !buf || cap <= 0) return fail("sbm_model_note: bad arguments");
+  std::strncpy(buf, m->pix_reason.c_str(), cap - 1); buf[cap - 1] = 0;
   return 0;
 }
 
@@ -491,8 +525,8 @@ int sbm_debug_pix_stamps(sbm_model* m, int first, int count, unsigned long long*
   if (!m->dp.use_pix) return fail("sbm_debug_pix_stamps: the pixel kernel is not in use for this model");
   for (int i = first; i < first + count; ++i) if (i < 0 || i >= (int)m->plan.ops.size() || !m->plan.ops[i].chain || m->plan.ops[i].time_path) return fail("sbm_debug_pix_stamps: not a run of pixel-kernel ops");
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 256));
-  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 256));
+  HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 512));
+  HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 512));
   for (int rep = 0; rep < 3; ++rep) {
     g_pix_dbg = d;
     const char* e = launch_pixrun(m->dp, first, count, m->own);
@@ -501,8 +535,8 @@ int sbm_debug_pix_stamps(sbm_model* m, int first, int count, unsigned long long*
     HIPCHK(hipStreamSynchronize(m->own));
   }
   const int n = pixrun_program_ops(m->dp, first, count, kinds, cap);
-  if (n < 0 || n + 1 > 256) { (void)hipFree(d); return fail("sbm_debug_pix_stamps: no such program"); }
-  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (cap < 256 ? cap : 256), hipMemcpyDeviceToHost));      // op stamps [0, n], phase stamps from 64
+  if (n < 0 || n + 1 > 128) { (void)hipFree(d); return fail("sbm_debug_pix_stamps: no such program (or more than 127 program ops)"); }
+  HIPCHK(hipMemcpy(out_host, d, sizeof(unsigned long long) * (cap < 512 ? cap : 512), hipMemcpyDeviceToHost));      // op stamps [0, n]; per GEMM pass (in program order) four phase stamps from 128
   (void)hipFree(d);
   *n_out = n;
   return 0;
@@ -534,7 +568,7 @@ int sbm_debug_profile_ops(sbm_model* m, const float* in_dev, const float* t_dev,
 }
 
 // Launches are issued exactly as run_plan issues them (a run of chain ops = ONE chain_kernel launch) and each carries its
-// own event pair; bucket k < 11 = op kind k launched as its own kernel, bucket 11 = chain_kernel.
+// own event pair; bucket k < 11 = op kind k launched as its own kernel, bucket 11 = chain_kernel, 13 = rowrun_kernel, 14 = pixrun_kernel.
 int sbm_model_profile(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int reps, double* ms_by_kind, int* launches_by_kind, int n_kinds) {
   return sbm_model_profile_mix(m, in_dev, t_dev, out_dev, reps, 0, ms_by_kind, launches_by_kind, n_kinds);
 }
@@ -568,7 +602,7 @@ int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev,
         while (i + n < nops && m->plan.ops[i + n].chain && !(skip_time && m->plan.ops[i + n].time_path)) ++n;
         if (n > CHAIN_MAX_OPS) n = CHAIN_MAX_OPS;              // one launch per event pair
         e = launch_chain(m->dp, i, n, st);
-        bucket.push_back(11);
+        bucket.push_back(m->dp.use_pix ? 14 : 11);
       } else if (m->plan.ops[i].row) {
         while (i + n < nops && m->plan.ops[i + n].row) ++n;
         e = launch_rowrun(m->dp, i, n, st);

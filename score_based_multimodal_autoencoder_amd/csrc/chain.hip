@@ -864,13 +864,9 @@ const char* chain_launch_geometry(int cus, int* grid, int* block) {
 }
 
 const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st) {
-  if (!dp.chain_ops || !dp.chain_sync) return "chain kernel: no op table";
   const Plan& plan = *dp.plan;
-  if (dp.use_pix) {                                   // the same ops as sample-owned workgroups (pixrun.hip); the time path stays here
-    bool time = false;
-    for (int i = first; i < first + count; ++i) time |= plan.ops[i].time_path != 0;
-    if (!time) return launch_pixrun(dp, first, count, st);
-  }
+  if (dp.use_pix) return launch_pixrun(dp, first, count, st);     // pixel mode: the marked ops are sample-owned workgroups (pixrun.hip); no chain tables exist
+  if (!dp.chain_ops || !dp.chain_sync) return "chain kernel: no op table";
   for (int i = first; i < first + count; ++i) {
     const Op& op = plan.ops[i];
     if (!op.chain) return "chain kernel: op is not marked for the chain";

@@ -130,6 +130,8 @@ const char* rowrun_prepare(const DevPlan& dp);
 extern unsigned long long* g_row_dbg;
 int rowrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap);   // diagnostics: kind * 1000 + passes per program op
 
+struct PixState;   // pixrun.hip: fragment-order weights and the programs of a model's low-resolution runs
+
 // A plan resolved against its device arenas.
 struct DevPlan {
   const Plan* plan = nullptr;
@@ -143,11 +145,12 @@ struct DevPlan {
   ChainCtl chain_ctl{};
   const StepCtl* ctl = nullptr;         // sampler control block (score nets)
   bool use_pix = false;                 // the chain-level ops run as sample-owned workgroups (pixrun.hip) instead of the chain kernel
+  PixState* pix = nullptr;              // ... and their state (owned by the model handle; released by pixrun_release)
 };
-// pixrun.hip: the 4x4 / 2x2 levels, one sample per workgroup, activations in LDS
+// pixrun.hip: the 4x4 / 2x2 / 1x1 levels, one sample per workgroup, activations in LDS
 const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st);
-const char* pixrun_prepare(const DevPlan& dp);
-void pixrun_release(const Plan* plan);
+const char* pixrun_prepare(DevPlan& dp, const float* host_params, double* frag_mb);   // host_params: the plan's packed weights (host copy)
+void pixrun_release(DevPlan& dp);
 extern unsigned long long* g_pix_dbg;
 int pixrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap);   // diagnostics: kind * 1000 + taps per program op
 const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st);
@@ -226,6 +229,9 @@ void launch_advance(int* step_counter, hipStream_t st);
 void launch_fill_normal(float* out, long long n_per_sample, int B, unsigned long long seed, unsigned long long sample_offset,
                         unsigned step, unsigned draw, float scale, hipStream_t st);
 void arm_profile_events(hipEvent_t start, hipEvent_t stop);
+// Raise a kernel's dynamic-LDS limit once per (function, device): the attribute is per device, so a process-wide flag would leave a second
+// device at the 64 KB default.  Cheap when already done (one device query + a set lookup under a mutex).
+void ensure_dynamic_lds(const void* fn, int bytes);
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;   // armed by arm_profile_events (kernels.hip)
 void launch_set_counter(int* step_counter, int value, hipStream_t st);
 void launch_axpy_noise(const StepArgs& a, float ca, float cb, float sdiv, unsigned mod_mask, int per_mod, hipStream_t st);

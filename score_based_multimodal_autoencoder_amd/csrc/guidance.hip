@@ -178,8 +178,7 @@ size_t clg_lds_bytes(int D0) { return sizeof(float) * CLG_TS * (size_t)(D0 + 2 *
 const char* launch_clg(const ClgArgs& a, hipStream_t st) {
   const size_t lds = clg_lds_bytes(a.D0);
   if (lds > 160 * 1024) return "guidance: the input width does not fit the LDS tile";
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(clg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(clg_kernel), 160 * 1024);
   hipLaunchKernelGGL(clg_kernel, dim3((a.B + CLG_TS - 1) / CLG_TS), dim3(CLG_NT), lds, st, a);
   return nullptr;
 }

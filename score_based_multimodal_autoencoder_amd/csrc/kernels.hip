@@ -7,6 +7,9 @@
 // LDS with a one-chunk register prefetch, GroupNorm(1,C) applied on the fly to A while it passes
 // through registers, bias / residual / activation / GroupNorm partial statistics fused in the epilogue.
 #include <hip/hip_runtime.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +26,17 @@
 // dispatch latency that a hipEventRecord pair around the launch would include.
 namespace sbm {
 thread_local hipEvent_t g_prof_start = nullptr, g_prof_stop = nullptr;
+void ensure_dynamic_lds(const void* fn, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({fn, dev})) return;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.insert({fn, dev});
+}
+
 void arm_profile_events(hipEvent_t start, hipEvent_t stop) { g_prof_start = start; g_prof_stop = stop; }
 }
 #define SBM_KLAUNCH(kern, grid, block, shmem, st, ...)                                                                      \
@@ -1628,8 +1642,7 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
         if (o.in.W != 16 || o.in.H != 16 || (o.in.C + 31) / 32 != o.stat_slabs || (o.in.C & 3)) return "dwconv7: slab statistics need a 16x16 tensor in slabs of 32 channels";
         SBM_KLAUNCH(dwconv7_t16_kernel, dim3(o.B, o.stat_slabs), dim3(256), 0, st, d);
       } else if (o.in.W == 8 && o.in.H == 8 && o.in.C / 4 <= 32 && !getenv("SBM_NO_DWT8")) {
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_t8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); attr_set = true; }
+        ensure_dynamic_lds(reinterpret_cast<const void*>(dwconv7_t8_kernel), 64 * 1024);
         SBM_KLAUNCH(dwconv7_t8_kernel, dim3(o.B), dim3(256), (size_t)(64 + 49) * (o.in.C / 4) * 16, st, d);
       } else if (o.in.W == 8 && o.in.C / 4 <= 64 && o.in.C / 4 >= 4 && (256 % (o.in.C / 4)) == 0 && !getenv("SBM_NO_DW8")) {
         SBM_KLAUNCH(dwconv7_w8_kernel, dim3(o.in.H * 2, ceil_div(o.B, d.spb)), dim3(256), 0, st, d);
@@ -1643,8 +1656,7 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       if (o.dh != 32) return "attention: dim_head must be 32";
       if (op.kind == OP_ATTN && a.n > 64) return "softmax attention: more than 64 positions";
       if (op.kind == OP_LINATTN && a.n > 16 && a.n <= 320 && (a.ldq & 3) == 0 && (a.n <= 64 || !getenv("SBM_NO_LINATTN_BIG"))) {
-        static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linattn_lds4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 320 * 128); attr_set = true; }     // + 18 KB static: within the 160 KB of a CU
+        ensure_dynamic_lds(reinterpret_cast<const void*>(linattn_lds4_kernel), 3 * 320 * 128);     // + 18 KB static: within the 160 KB of a CU
         SBM_KLAUNCH(linattn_lds4_kernel, dim3(o.B * o.heads), dim3(256), (size_t)3 * a.n * 128, st, a);
       }
       else if (op.kind == OP_LINATTN && a.n <= 64 && (a.ldq & 3) == 0) SBM_KLAUNCH(linattn_lds_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);

@@ -1,30 +1,37 @@
-// pixrun.hip -- the 4x4 and 2x2 levels of the score net as launches of SAMPLE-OWNED workgroups.
+// pixrun.hip -- the low-resolution levels of the score net (4x4, 2x2, 1x1) as ONE launch of SAMPLE-OWNED workgroups.
 //
-// The XCD-resident chain kernel (chain.hip) carries a 32-sample tile through the low-resolution ops with a cluster barrier after every
-// op: 57 barriers and as many first-touch weight latencies per step, 0.57 ms for 21 GFLOP.  Nothing in the network mixes samples, so
-// this kernel gives a workgroup ONE sample and lets it run through the whole op list alone: no barrier ever leaves the workgroup, the
-// sample's activations live in LDS from the first op to the last, and the level's weights are streamed from L2 -- all workgroups of an
-// XCD walk the same bytes in the same order, so the L2 serves 31 of 32 readers (tools/stream_probe.hip: 256 workgroups x 9.5 MB in
-// 178 us while issuing the MFMAs below = 13.7 TB/s out of the L2s, 109 TFLOP/s).
+// Nothing in the network mixes samples, so a workgroup takes ONE sample through the whole run of low-resolution ops alone: no barrier
+// ever leaves the workgroup, the sample's activations stay in LDS from the first op to the last, and the run's weights are streamed
+// from L2 (all workgroups of an XCD walk the same bytes in the same order).  Round 3 rewrite; what the measurements behind it say
+// (tools/pixgemm_probe.hip, profiles/r03_pixgemm_probe.txt):
 //
-//   rows      : the PIXELS of the sample are the M rows of v_mfma_f32_16x16x4_f32 (16 pixels at 4x4; at 2x2 rows 4..15 are idle)
-//   activations: LDS slab T[k >> 4][row][16], the 16 channels of a chunk stored at position (k & 3) * 4 + ((k >> 2) & 3): lane
-//               (row = l & 15, g = l >> 4) reads ONE float4 = A[row][16 c + 4 j + g], j = 0..3, the operands of four MFMAs
-//   taps      : a convolution tap is a row gather: lane's source row = src[tap][row] (or the zero row) -- padding, stride, transposed
-//               convolution and nearest upsampling are all just row tables built on the host
-//   weights   : transposed copies [tap][k][n] (n contiguous): lane (q = l & 15, g) loads W[16 c + 4 j + g][n0 + 4 q .. + 3], j = 0..3;
-//               accumulator i of four holds column n0 + 4 q + i (rows 4 g + v in VGPR v)
-//   waves     : a pass covers 1, 2 or 4 blocks of 64 columns; the waves of a block split K and meet in LDS
-//   epilogue  : 512 threads = 16 rows x 32 column pairs per block; folded GroupNorm, bias, residual, activation, LDS + global store
+//   weights   : streamed in MFMA FRAGMENT order, packed on the host at model creation, so that every wave-load is 1 KB contiguous:
+//               118 GB/s per workgroup (30 TB/s out of the L2s) against 37 GB/s for 64-byte row segments of a [n][k] matrix.
+//   ring      : a wave keeps D = 4 steps of 4 KB in flight in AGPRs with hard-coded indices, loaded and consumed by inline asm (the MFMA
+//               takes its B operand straight from the AGPR) behind hand-counted s_waitcnt vmcnt.  hipcc cannot be asked for this: its
+//               own loads are clustered at the end of the unrolled body and waited for with vmcnt(0), and asm loads into registers IT
+//               allocates get copied (v_mov in a peeled iteration) before the hand-placed wait -- silently wrong values.
+//   steps     : the K loop of every GEMM is a host-built table of steps {weight block, LDS chunk | row table}, dealt to the wave groups
+//               that split K and padded to a multiple of D with no-op steps; the loader simply runs D steps ahead of the consumer ACROSS
+//               op boundaries, so the next GEMM's first weights are in flight under this one's reduction and epilogue.
+//   MFMA      : >= 2 independent accumulators per wave (one dependent chain per wave does NOT reach the issue rate at 2 waves per SIMD:
+//               98 vs 153 TFLOP/s).  16 output rows (4x4): v_mfma_f32_16x16x4_f32, a wave owns 32 columns (2 accumulators); the K loop
+//               then runs at the matrix pipe's issue limit.  <= 4 output rows (2x2, 1x1): v_mfma_f32_4x4x1_16b_f32, 16 blocks = 16
+//               column quads sharing one k, a wave owns 64 columns, even / odd k in two accumulators -- a quarter of the issue time
+//               per weight byte, which makes these levels L2-stream bound instead of matrix-pipe bound.
+//   rows      : activations live in LDS slabs T[k >> 4][17 rows][16 k]; row 16 of every chunk is never written and stays zero: the
+//               source of padding taps and idle rows, so a tap is a plain row gather (row table per tap, built on the host) with no
+//               branch.  Padding, stride, transposed convolution, nearest upsampling and the fused 1x1 residual conv are all tables.
 //
-// Every output is also stored to the workspace in the plan's [P][B][ld] layout: skip connections, the ops behind the run and the
-// op-by-op debug tools find it where the other paths would have put it.
+// Everything belongs to the model handle (PixState, owned by DevPlan): no process-global maps.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -35,32 +42,35 @@ namespace sbm {
 namespace {
 
 typedef float f32x4p __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) f32x4p gf32x4p;
 
-constexpr int PNT = 512, PNW = 8;
+constexpr int PNT = 512, PNW = 8;         // threads / waves per workgroup (2 waves per SIMD)
+constexpr int PD = 4;                     // ring depth in steps (4 KB per wave and step)
+constexpr int PCS = 272;                  // floats per LDS chunk: 17 rows x 16 k
 constexpr int PIX_STAGE = 101;
-constexpr int P_RING = 4;                 // weight chunks (16 k x 64 columns = 4 dwordx4 per lane) in flight per wave
-constexpr int P_ZERO_F = 64, P_RED_F = PNW * 16 * 64, P_STAT_SLOTS = 64, P_SCR_F = 4352, P_MAXTAP = 20, P_TAP_I = 12;
+constexpr int P_RED_F = PNW * 512, P_STAT_SLOTS = 64, P_SCR_F = 4352;
 
-struct PixTap { int w_off, a_lds, a_cs, nch, src2, pad0, pad1, pad2; int src[4]; };   // src: 16 signed bytes, source row of output row r (-1: none)
-static_assert(sizeof(PixTap) == P_TAP_I * 4, "PixTap is staged to LDS as 12 ints");
+struct PixStep { unsigned w_off; unsigned a_sel; };   // w_off: float offset (fragment arena) of the step's block for column group 0 of the pass;
+                                                      // a_sel = LDS float offset of the step's first chunk | row table << 16 | source 2 << 31
+struct PixItem {                          // one pass of a GEMM: up to 8 column groups (32 columns, or 64 on the 4-row path)
+  int step_base, nkp;                     // step lists of the K slices: step_base + slice * nkp, nkp a multiple of PD
+  int gshift, kshift;                     // log2(column groups of the pass), log2(K slices) -- groups * slices = 8 waves
+  int grp0, grp_stride;                   // first column group; floats between the blocks of consecutive groups
+  int small, pad;                         // 1: the 4-row path
+};
 
 struct PixOpD {
   int kind;                              // OP_GEMM, OP_DWCONV7, OP_GN_RES, OP_LINATTN, PIX_STAGE
-  int P_out, Npad, nstore, act, ldo, nblk;
+  int item0, nitems;                     // GEMM: its passes
+  int P_out, Npad, nstore, act, ldo, nblk, scale2;
   int gn_stat, stat_out;                 // LDS statistics slots consumed / produced, -1 none
-  int in_lds, in_cs, out_lds, out_cs, res_lds, res_cs;
-  int res_row[4];                        // 16 signed bytes: residual row of output row r
-  int tap_first, tap_cnt;
-  const float* pf_ptr; int pf_lines;     // L2 warm-up: the first weight lines of the NEXT GEMM op of the program (touched under this op's epilogue)
-  int k_ntap1, k_nch1, k_nch2;           // source-1 taps and their common chunk count; chunks of the source-2 tap (0: none)
+  int in_lds, out_lds, res_lds, x_lds;
+  int res_row[4];                        // 16 bytes: residual row of output row r
   float gn_inv;
-  const float* Wt; const float* Wt2; const PixTap* taps;
-  const float* bias; const float* gn_s; const float* gn_b1;
+  const float* bias; const float* gn_s; const float* gn_b1;     // never null: a zero vector stands in
+  int gn_rowstride;                      // Npad (folded GroupNorm tables are per output pixel) or 0
   float* out_g; float2* stat_g;
   DwArgs dw; GnResArgs gr; AttnArgs at;
-  int x_lds, x_cs;                       // GN_RES: the residual input x
-  const float* st_src; const float2* st_part; int st_ld, st_C, st_P, st_lds, st_cs, st_stat, st_nparts;
+  const float* st_src; const float2* st_part; int st_ld, st_C, st_P, st_lds, st_stat, st_nparts;
 };
 
 __device__ __forceinline__ float pix_act(int act, float v) {
@@ -75,37 +85,124 @@ __device__ __forceinline__ float pix_act(int act, float v) {
     default: return v;
   }
 }
-// float offset of channel k of row r inside a slab with chunk stride cs
-__device__ __forceinline__ int pix_at(int k, int r, int cs) { return (k >> 4) * cs + r * 16 + (k & 3) * 4 + ((k >> 2) & 3); }
+// The step / item / op tables are read through the CONSTANT address space: with a uniform address that is always a scalar load (s_load).
+// Read as ordinary global memory they turn into vector loads -- the kernel stores through pointers it has loaded (op.out_g, ...), so hipcc
+// cannot prove the tables unclobbered -- and every vector load drags a compiler-placed s_waitcnt vmcnt(0) into the K loop, which drains
+// the weight ring.
+typedef int i32x2p __attribute__((ext_vector_type(2)));
+typedef int i32x8p __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ PixStep ldc_step(const PixStep* p) {
+  const i32x2p v = *(const __attribute__((address_space(4))) i32x2p*)(unsigned long long)p;
+  return PixStep{(unsigned)v[0], (unsigned)v[1]};
+}
+__device__ __forceinline__ PixItem ldc_item(const PixItem* p) {
+  const i32x8p v = *(const __attribute__((address_space(4))) i32x8p*)(unsigned long long)p;
+  PixItem it; it.step_base = v[0]; it.nkp = v[1]; it.gshift = v[2]; it.kshift = v[3]; it.grp0 = v[4]; it.grp_stride = v[5]; it.small = v[6]; it.pad = v[7];
+  return it;
+}
+template <typename T> __device__ __forceinline__ T ldc(const T* p) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "ldc: 4- or 8-byte fields");
+  if constexpr (sizeof(T) == 4) { const int v = *(const __attribute__((address_space(4))) int*)(unsigned long long)p; T r; __builtin_memcpy(&r, &v, 4); return r; }
+  else { const i32x2p v = *(const __attribute__((address_space(4))) i32x2p*)(unsigned long long)p; T r; __builtin_memcpy(&r, &v, 8); return r; }
+}
+// float offset of channel k of row r inside a slab
+__device__ __forceinline__ int pix_at(int k, int r) { return (k >> 4) * PCS + r * 16 + (k & 15); }
 __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed char)((w[r >> 2] >> (8 * (r & 3))) & 0xff); }
+
+// ---- the weight ring: AGPRs a[16 r .. 16 r + 15] = slot r (four dwordx4 of one step); epilogue operands: a[64 .. 87] ----
+#define PIX_CLOB_0 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15"
+#define PIX_CLOB_1 "a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31"
+#define PIX_CLOB_2 "a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"
+#define PIX_CLOB_3 "a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
+#define PIX_CLOB_E "a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87"
+#define PIX_RING_LOAD(voff, base, A0, A3, A4, A7, A8, A11, A12, A15, CLOB) \
+  asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, %1\n\t" \
+               "global_load_dwordx4 a[" #A4 ":" #A7 "], %0, %1 offset:1024\n\t" \
+               "global_load_dwordx4 a[" #A8 ":" #A11 "], %0, %1 offset:2048\n\t" \
+               "global_load_dwordx4 a[" #A12 ":" #A15 "], %0, %1 offset:3072" \
+               :: "v"(voff), "s"(base) : CLOB)
+#define PIX_LOAD_SLOT(r, base_, off) do { \
+    if ((r) == 0) PIX_RING_LOAD(off, base_, 0, 3, 4, 7, 8, 11, 12, 15, PIX_CLOB_0); \
+    else if ((r) == 1) PIX_RING_LOAD(off, base_, 16, 19, 20, 23, 24, 27, 28, 31, PIX_CLOB_1); \
+    else if ((r) == 2) PIX_RING_LOAD(off, base_, 32, 35, 36, 39, 40, 43, 44, 47, PIX_CLOB_2); \
+    else PIX_RING_LOAD(off, base_, 48, 51, 52, 55, 56, 59, 60, 63, PIX_CLOB_3); } while (0)
+// vmcnt(12): the three other slots' loads (12) are always issued behind a slot's own four before it is consumed again -- the loader never
+// skips a step -- and anything else in flight (epilogue operands, stores, the compiler's own loads) only makes the wait stricter.
+#define PIX_MF16(ACC, A, B) "v_mfma_f32_16x16x4_f32 " ACC ", " A ", a" #B ", " ACC "\n\t"
+#define PIX_MFMA16(acc0, acc1, a0, a1, B0, B1, B2, B3, B4, B5, B6, B7, B8, B9, B10, B11, B12, B13, B14, B15) \
+  asm volatile("s_waitcnt vmcnt(12)\n\t" \
+               PIX_MF16("%0", "%2", B0) PIX_MF16("%1", "%2", B4) PIX_MF16("%0", "%3", B1) PIX_MF16("%1", "%3", B5) PIX_MF16("%0", "%4", B2) PIX_MF16("%1", "%4", B6) PIX_MF16("%0", "%5", B3) PIX_MF16("%1", "%5", B7) \
+               PIX_MF16("%0", "%6", B8) PIX_MF16("%1", "%6", B12) PIX_MF16("%0", "%7", B9) PIX_MF16("%1", "%7", B13) PIX_MF16("%0", "%8", B10) PIX_MF16("%1", "%8", B14) PIX_MF16("%0", "%9", B11) "v_mfma_f32_16x16x4_f32 %1, %9, a" #B15 ", %1" \
+               : "+v"(acc0), "+v"(acc1) : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]))
+#define PIX_MFMA16_SLOT(r, a0, a1) do { \
+    if ((r) == 0) PIX_MFMA16(acc0, acc1, a0, a1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15); \
+    else if ((r) == 1) PIX_MFMA16(acc0, acc1, a0, a1, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31); \
+    else if ((r) == 2) PIX_MFMA16(acc0, acc1, a0, a1, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47); \
+    else PIX_MFMA16(acc0, acc1, a0, a1, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63); } while (0)
+#define PIX_MF4(ACC, A, B) "v_mfma_f32_4x4x1_16b_f32 " ACC ", " A ", a" #B ", " ACC "\n\t"
+#define PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, B0, B1, B2, B3, B4, B5, B6, B7, B8, B9, B10, B11, B12, B13, B14, B15) \
+  asm volatile("s_waitcnt vmcnt(12)\n\t" \
+               PIX_MF4("%0", "%2", B0) PIX_MF4("%1", "%3", B1) PIX_MF4("%0", "%4", B2) PIX_MF4("%1", "%5", B3) PIX_MF4("%0", "%6", B4) PIX_MF4("%1", "%7", B5) PIX_MF4("%0", "%8", B6) PIX_MF4("%1", "%9", B7) \
+               PIX_MF4("%0", "%10", B8) PIX_MF4("%1", "%11", B9) PIX_MF4("%0", "%12", B10) PIX_MF4("%1", "%13", B11) PIX_MF4("%0", "%14", B12) PIX_MF4("%1", "%15", B13) PIX_MF4("%0", "%16", B14) "v_mfma_f32_4x4x1_16b_f32 %1, %17, a" #B15 ", %1" \
+               : "+v"(acc0), "+v"(acc1) : "v"(q0[0]), "v"(q0[1]), "v"(q0[2]), "v"(q0[3]), "v"(q1[0]), "v"(q1[1]), "v"(q1[2]), "v"(q1[3]), \
+                 "v"(q2[0]), "v"(q2[1]), "v"(q2[2]), "v"(q2[3]), "v"(q3[0]), "v"(q3[1]), "v"(q3[2]), "v"(q3[3]))
+#define PIX_MFMA4_SLOT(r) do { \
+    if ((r) == 0) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15); \
+    else if ((r) == 1) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31); \
+    else if ((r) == 2) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47); \
+    else PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63); } while (0)
+// epilogue operands of one output quad: bias, folded-GroupNorm S and B1 (three dwordx4) into a[BASE .. BASE + 11]
+#define PIX_ELOAD(pb, ps, pg, A0, A3, A4, A7, A8, A11) \
+  asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off\n\t" \
+               "global_load_dwordx4 a[" #A4 ":" #A7 "], %1, off\n\t" \
+               "global_load_dwordx4 a[" #A8 ":" #A11 "], %2, off" \
+               :: "v"(pb), "v"(ps), "v"(pg) : PIX_CLOB_E)
+#define PIX_EREAD4(dst, A0, A1, A2, A3) \
+  asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3 \
+               : "=v"(dst[0]), "=v"(dst[1]), "=v"(dst[2]), "=v"(dst[3]))
 
 }  // namespace
 
-__global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict__ ops, int count, int B, int act_floats, const PixTap* __restrict__ taps, int ntaps, unsigned long long* dbg) {
+__global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict__ ops, int count, const PixItem* __restrict__ items, int nitems, const PixStep* __restrict__ steps,
+                                                        const unsigned char* __restrict__ rowtab, int nrowtab, const float* __restrict__ frag, int B, int act_floats,
+                                                        unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* zero = lds + act_floats;                        // P_ZERO_F zeros: the source of rows a tap does not reach
-  float* red = zero + P_ZERO_F;                          // [8 waves][16 rows][64 columns]
+  float* red = lds + act_floats;                         // [8 waves][512]: 16 rows x 32 columns, or 4 rows x 64 columns
   float* stat = red + P_RED_F;                           // [slots][2]
   float* scr = stat + P_STAT_SLOTS * 2;                  // scratch (LinearAttention contexts, reductions)
-  int* tap_all = reinterpret_cast<int*>(scr + P_SCR_F);  // the tap tables of the whole program, staged once
+  unsigned char* rtab = reinterpret_cast<unsigned char*>(scr + P_SCR_F);   // [nrowtab][16]: source row of output row r (16 = the zero row)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
-  const int q = lane & 15, g = lane >> 4;
-  unsigned sink = 0;
-  for (int i = tid; i < act_floats + P_ZERO_F + P_RED_F; i += PNT) lds[i] = 0.f;
-  for (int i = tid; i < ntaps * P_TAP_I; i += PNT) tap_all[i] = reinterpret_cast<const int*>(taps)[i];
+  for (int i = tid; i < act_floats + P_RED_F; i += PNT) lds[i] = 0.f;
+  for (int i = tid; i < nrowtab * 16; i += PNT) rtab[i] = rowtab[i];
   __syncthreads();
+  // ---- loader state (per wave; survives the non-GEMM ops between two GEMMs) ----
+  unsigned asel[PD];
+  auto lane_off = [&](const PixItem& it) { return (unsigned)(((wave & ((1 << it.gshift) - 1)) * it.grp_stride + lane * 4) * 4); };   // bytes
+  auto slice_steps = [&](const PixItem& it) { return steps + it.step_base + (wave >> it.gshift) * it.nkp; };
+  int ci = 0;
+  PixItem cur = ldc_item(items);
+  unsigned off_c = lane_off(cur);
+  const PixStep* st_c = slice_steps(cur);
+  {
+#pragma unroll
+    for (int r = 0; r < PD; ++r) {
+      const PixStep e = ldc_step(st_c + r);
+      asel[r] = e.a_sel;
+      const float* base_ = frag + e.w_off;
+      PIX_LOAD_SLOT(r, base_, off_c);
+    }
+  }
   for (int k = 0; k < count; ++k) {
     const PixOpD& op = ops[k];
-    const int kind = op.kind;
+    const int kind = ldc(&op.kind);
     if (dbg && b == 0 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();
     if (kind == PIX_STAGE) {
       const int C4 = op.st_C >> 2;
       for (int idx = tid; idx < op.st_P * C4; idx += PNT) {
         const int c4 = idx % C4, p = idx / C4;
         const float4 v = *reinterpret_cast<const float4*>(op.st_src + ((long long)p * B + b) * op.st_ld + 4 * c4);
-        float* d = lds + op.st_lds + ((4 * c4) >> 4) * op.st_cs + p * 16 + (c4 & 3);     // k = 4 c4 + e: position e * 4 + (c4 & 3)
-        d[0] = v.x; d[4] = v.y; d[8] = v.z; d[12] = v.w;
+        *reinterpret_cast<float4*>(lds + op.st_lds + pix_at(4 * c4, p)) = v;
       }
       if (op.st_stat >= 0 && tid == 0) {
         double s = 0.0, qq = 0.0;
@@ -116,35 +213,43 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       continue;
     }
     if (kind == OP_DWCONV7) {
-      // depth-wise 7x7 over an image of at most 4x4: the window covers the whole image, so an output walks the source pixels in raster
-      // order (= tap order).  Thread = (channel, every tpc-th pixel).
+      // depth-wise 7x7 over an image of at most 4x4: the window covers the whole image.  Task = (channel, output row py): its W outputs
+      // need the H x (2 W - 1) weights w[qy - py + 3][d + 3], each loaded once (coalesced over the channels), and the channel's H W inputs.
       const DwArgs& d = op.dw;
-      const int C = d.C, P = d.H * d.W, tpc = PNT / C;
-      const int c = tid % C, pg = tid / C;
-      const float bi = d.bias[c];
-      const float cv = d.cond ? dw_cond_row(d, b)[c] : 0.f;
+      const int C = d.C, H = d.H, W = d.W, P = H * W;
       float s = 0.f, qq = 0.f;
-      if (pg < tpc) {
-        for (int p = pg; p < P; p += tpc) {
-          const int py = p / d.W, px = p - py * d.W;
-          float acc = 0.f;
-          for (int q0 = 0; q0 < P; q0 += 4) {             // P is 4 or 16 (or 1): four independent weight loads in flight
-            float xv[4], wv[4];
+      for (int task = tid; task < C * H; task += PNT) {
+        const int c = task % C, py = task / C;
+        float wv[4][7], xv[4][4], acc[4];
+        const float bi = d.bias[c] + (d.cond ? dw_cond_row(d, b)[c] : 0.f);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int qp = min(q0 + j, P - 1), qy = qp / d.W, qx = qp - qy * d.W;
-              wv[j] = d.w[((qy - py + 3) * 7 + (qx - px + 3)) * C + c];
-              xv[j] = lds[op.in_lds + pix_at(c, qp, op.in_cs)];
-            }
+        for (int qy = 0; qy < 4; ++qy)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (q0 + j < P) acc = fmaf(xv[j], wv[j], acc);
+          for (int dx = 0; dx < 7; ++dx) {
+            const bool live = qy < H && dx >= 4 - W && dx <= 2 + W;
+            wv[qy][dx] = live ? d.w[((qy - py + 3) * 7 + dx) * C + c] : 0.f;
           }
-          acc += bi;
-          if (d.cond) acc += cv;
-          lds[op.out_lds + pix_at(c, p, op.out_cs)] = acc;
-          if (op.out_g) d.out[((long long)p * B + b) * d.ldo + c] = acc;
-          s += acc; qq += acc * acc;
+#pragma unroll
+        for (int qy = 0; qy < 4; ++qy)
+#pragma unroll
+          for (int qx = 0; qx < 4; ++qx) xv[qy][qx] = (qy < H && qx < W) ? lds[op.in_lds + pix_at(c, qy * W + qx)] : 0.f;
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+          float a = 0.f;
+#pragma unroll
+          for (int qy = 0; qy < 4; ++qy)
+#pragma unroll
+            for (int qx = 0; qx < 4; ++qx) a = fmaf(xv[qy][qx], wv[qy][qx - px + 3], a);     // rows / columns beyond the image carry zeros
+          acc[px] = a + bi;
         }
+#pragma unroll
+        for (int px = 0; px < 4; ++px)
+          if (px < W) {
+            const int p = py * W + px;
+            lds[op.out_lds + pix_at(c, p)] = acc[px];
+            if (op.out_g) d.out[((long long)p * B + b) * d.ldo + c] = acc[px];
+            s += acc[px]; qq += acc[px] * acc[px];
+          }
       }
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m); qq += __shfl_xor(qq, m); }
@@ -168,12 +273,16 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       const double mean_d = (double)su * (double)gr.inv_count;
       double var = (double)sq * (double)gr.inv_count - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
       const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + 1e-5));
-      for (int idx = tid; idx < gr.P * gr.C; idx += PNT) {
-        const int c = idx % gr.C, p = idx / gr.C;
-        const float u = lds[op.in_lds + pix_at(c, p, op.in_cs)], x = lds[op.x_lds + pix_at(c, p, op.x_cs)];
-        const float y = ((u - mean) * rstd) * gr.gamma[c] + gr.beta[c] + x;
-        lds[op.out_lds + pix_at(c, p, op.out_cs)] = y;
-        if (op.out_g) gr.out[((long long)p * B + b) * gr.ldo + c] = y;
+      const int C4 = gr.C >> 2;
+      for (int idx = tid; idx < gr.P * C4; idx += PNT) {
+        const int c4 = idx % C4, p = idx / C4;
+        const float4 u = *reinterpret_cast<const float4*>(lds + op.in_lds + pix_at(4 * c4, p)), x = *reinterpret_cast<const float4*>(lds + op.x_lds + pix_at(4 * c4, p));
+        const float4 ga = *reinterpret_cast<const float4*>(gr.gamma + 4 * c4), be = *reinterpret_cast<const float4*>(gr.beta + 4 * c4);
+        float4 y;
+        y.x = ((u.x - mean) * rstd) * ga.x + be.x + x.x; y.y = ((u.y - mean) * rstd) * ga.y + be.y + x.y;
+        y.z = ((u.z - mean) * rstd) * ga.z + be.z + x.z; y.w = ((u.w - mean) * rstd) * ga.w + be.w + x.w;
+        *reinterpret_cast<float4*>(lds + op.out_lds + pix_at(4 * c4, p)) = y;
+        if (op.out_g) *reinterpret_cast<float4*>(gr.out + ((long long)p * B + b) * gr.ldo + 4 * c4) = y;
       }
       __syncthreads();
       continue;
@@ -181,22 +290,22 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     if (kind == OP_LINATTN) {
       // LinearAttention core (unet_model.py:169-175) of one sample: n <= 16 positions, heads x 32 channels; q | k | v in one slab
       const AttnArgs& a = op.at;
-      const int n = a.n, hd = a.heads * 32, ics = op.in_cs;
+      const int n = a.n, hd = a.heads * 32;
       if (tid < hd) {                                    // k: softmax over the positions, per channel
         float m = -INFINITY;
-        for (int p = 0; p < n; ++p) m = fmaxf(m, lds[op.in_lds + pix_at(hd + tid, p, ics)]);
+        for (int p = 0; p < n; ++p) m = fmaxf(m, lds[op.in_lds + pix_at(hd + tid, p)]);
         float z = 0.f;
-        for (int p = 0; p < n; ++p) { const float e = expf(lds[op.in_lds + pix_at(hd + tid, p, ics)] - m); lds[op.in_lds + pix_at(hd + tid, p, ics)] = e; z += e; }
+        for (int p = 0; p < n; ++p) { const float e = expf(lds[op.in_lds + pix_at(hd + tid, p)] - m); lds[op.in_lds + pix_at(hd + tid, p)] = e; z += e; }
         const float inv = 1.0f / z;
-        for (int p = 0; p < n; ++p) lds[op.in_lds + pix_at(hd + tid, p, ics)] *= inv;
+        for (int p = 0; p < n; ++p) lds[op.in_lds + pix_at(hd + tid, p)] *= inv;
       } else if (tid >= 256 && tid < 256 + n * a.heads) {   // q: softmax over the head's channels, per position; scaled
         const int t = tid - 256, p = t / a.heads, h = t - p * a.heads;
         float m = -INFINITY;
-        for (int dd = 0; dd < 32; ++dd) m = fmaxf(m, lds[op.in_lds + pix_at(h * 32 + dd, p, ics)]);
+        for (int dd = 0; dd < 32; ++dd) m = fmaxf(m, lds[op.in_lds + pix_at(h * 32 + dd, p)]);
         float z = 0.f;
-        for (int dd = 0; dd < 32; ++dd) { const float e = expf(lds[op.in_lds + pix_at(h * 32 + dd, p, ics)] - m); lds[op.in_lds + pix_at(h * 32 + dd, p, ics)] = e; z += e; }
+        for (int dd = 0; dd < 32; ++dd) { const float e = expf(lds[op.in_lds + pix_at(h * 32 + dd, p)] - m); lds[op.in_lds + pix_at(h * 32 + dd, p)] = e; z += e; }
         const float inv = a.scale / z;
-        for (int dd = 0; dd < 32; ++dd) lds[op.in_lds + pix_at(h * 32 + dd, p, ics)] *= inv;
+        for (int dd = 0; dd < 32; ++dd) lds[op.in_lds + pix_at(h * 32 + dd, p)] *= inv;
       }
       __syncthreads();
       // context[h][d][e] = sum_p k[p][h, d] v[p][h, e]: thread = (h, d, 8 consecutive e)
@@ -206,9 +315,10 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) cx[e] = 0.f;
         for (int p = 0; p < n; ++p) {
-          const float kv = lds[op.in_lds + pix_at(hd + h * 32 + dd, p, ics)];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) cx[e] = fmaf(kv, lds[op.in_lds + pix_at(2 * hd + h * 32 + e0 + e, p, ics)], cx[e]);
+          const float kv = lds[op.in_lds + pix_at(hd + h * 32 + dd, p)];
+          const float4 v0 = *reinterpret_cast<const float4*>(lds + op.in_lds + pix_at(2 * hd + h * 32 + e0, p)), v1 = *reinterpret_cast<const float4*>(lds + op.in_lds + pix_at(2 * hd + h * 32 + e0 + 4, p));
+          cx[0] = fmaf(kv, v0.x, cx[0]); cx[1] = fmaf(kv, v0.y, cx[1]); cx[2] = fmaf(kv, v0.z, cx[2]); cx[3] = fmaf(kv, v0.w, cx[3]);
+          cx[4] = fmaf(kv, v1.x, cx[4]); cx[5] = fmaf(kv, v1.y, cx[5]); cx[6] = fmaf(kv, v1.z, cx[6]); cx[7] = fmaf(kv, v1.w, cx[7]);
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) scr[(h * 32 + dd) * 33 + e0 + e] = cx[e];
@@ -218,181 +328,159 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       for (int t = tid; t < n * hd; t += PNT) {
         const int ch = t % hd, p = t / hd, h = ch >> 5, e = ch & 31;
         float o = 0.f;
-        for (int dd = 0; dd < 32; ++dd) o = fmaf(lds[op.in_lds + pix_at(h * 32 + dd, p, ics)], scr[(h * 32 + dd) * 33 + e], o);
-        lds[op.out_lds + pix_at(ch, p, op.out_cs)] = o;
+        for (int dd = 0; dd < 32; ++dd) o = fmaf(lds[op.in_lds + pix_at(h * 32 + dd, p)], scr[(h * 32 + dd) * 33 + e], o);
+        lds[op.out_lds + pix_at(ch, p)] = o;
         if (op.out_g) a.out[((long long)p * B + b) * a.ldo + ch] = o;
       }
       __syncthreads();
       continue;
     }
     // ---------------------------------------------------------------- GEMM
-#define PSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && k < 30) dbg[64 + k * 6 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
-    PSTAMP(0);
-    const int* tapl = tap_all + op.tap_first * P_TAP_I;
-    const bool gn = op.gn_stat >= 0;
+#define PSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && ci < 60) dbg[128 + ci * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+    // every field of the op the GEMM path touches, through scalar loads
+    const int g_nitems = ldc(&op.nitems), g_P_out = ldc(&op.P_out), g_Npad = ldc(&op.Npad), g_nstore = ldc(&op.nstore), g_act = ldc(&op.act), g_ldo = ldc(&op.ldo), g_nblk = ldc(&op.nblk);
+    const int g_gn_stat = ldc(&op.gn_stat), g_stat_out = ldc(&op.stat_out), g_out_lds = ldc(&op.out_lds), g_res_lds = ldc(&op.res_lds), g_rowstride = ldc(&op.gn_rowstride);
+    const int g_res_row[4] = {ldc(&op.res_row[0]), ldc(&op.res_row[1]), ldc(&op.res_row[2]), ldc(&op.res_row[3])};
+    const float* g_bias = ldc(&op.bias); const float* g_gn_s = ldc(&op.gn_s); const float* g_gn_b1 = ldc(&op.gn_b1);
+    float* g_out_g = ldc(&op.out_g); float2* g_stat_g = ldc(&op.stat_g);
+    const bool gn = g_gn_stat >= 0;
     float mean = 0.f, rstd = 1.f, inv_r = 1.f;
     if (gn) {
-      const float su = stat[op.gn_stat * 2], sq = stat[op.gn_stat * 2 + 1];
-      const double mean_d = (double)su * (double)op.gn_inv;
-      double var = (double)sq * (double)op.gn_inv - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
+      const float su = stat[g_gn_stat * 2], sq = stat[g_gn_stat * 2 + 1];
+      const double mean_d = (double)su * (double)ldc(&op.gn_inv);
+      double var = (double)sq * (double)ldc(&op.gn_inv) - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
       mean = (float)mean_d; rstd = rsqrtf((float)var + 1e-5f); inv_r = sqrtf((float)var + 1e-5f);
     }
-    const int nb = (op.nstore + 63) >> 6, ntap = op.tap_cnt, npad = op.Npad;
-    // At most four output rows (the 2x2 level): v_mfma_f32_4x4x1_16b_f32 -- 16 independent 4x4 outer products per issue, rows = the four
-    // pixels, one k per lane group g -- at a quarter of the 16x16x4 issue time per weight byte: these layers become L2-streaming bound.
-    // The four lane groups hold partial sums over disjoint k and meet in the LDS reduction with the waves' K slices.
-    const bool small = __builtin_amdgcn_readfirstlane(op.P_out) <= 4;
-    const int erow = tid >> 5, ec2 = (tid & 31) * 2;     // epilogue: this thread's row and column pair inside a block
-    const int rrow = op.res_lds >= 0 ? sbyte(op.res_row, erow) : 0;
+    const bool scale2 = ldc(&op.scale2) != 0;            // folded GroupNorm + fused source-2 conv: source 2 enters unnormalised (x 1 / rstd, undone by the row scaling)
     float sacc = 0.f, qacc = 0.f;
-    for (int cb0 = 0; cb0 < nb;) {
-      const int rem = nb - cb0, par = rem >= 4 ? 4 : (rem >= 2 ? 2 : 1);
-      const int ksh = par == 4 ? 1 : (par == 2 ? 2 : 3);   // waves per block = K slices = 8 / par, as a shift (no integer divisions in the set-up)
-      const int ksplit = 1 << ksh, wblk = wave >> ksh, wk = wave & (ksplit - 1);
-      const int col = min((cb0 + wblk) * 64 + 4 * q, npad - 4);
-      // epilogue operands of this thread's outputs, asked for before the K loop
-      float2 e_b[4], e_s[4], e_g[4];
+    for (int it = 0; it < g_nitems; ++it) {
+      const int ni = ci + 1 < nitems ? ci + 1 : 0;
+      const PixItem nxt = ldc_item(items + ni);
+      const unsigned off_n = lane_off(nxt);
+      const PixStep* st_n = slice_steps(nxt);
+      const bool small = cur.small != 0;
+      // output quads of this thread (row, 4 columns) and their epilogue operands, requested before the K loop
+      const int gw = small ? 64 : 32, qshift = cur.gshift + (small ? 4 : 3), total = g_P_out << qshift;
+      int e_row[2], e_col[2]; bool e_ok[2];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        e_b[j] = e_s[j] = e_g[j] = make_float2(0.f, 0.f);
-        const int n = (cb0 + j) * 64 + ec2;
-        if (j < par && n < op.nstore && erow < op.P_out) {
-          if (op.bias) e_b[j] = *reinterpret_cast<const float2*>(op.bias + n);
-          if (gn) { e_s[j] = *reinterpret_cast<const float2*>(op.gn_s + (long long)erow * npad + n); e_g[j] = *reinterpret_cast<const float2*>(op.gn_b1 + (long long)erow * npad + n); }
+      for (int q = 0; q < 2; ++q) {
+        const int idx = tid + q * PNT, idc = idx < total ? idx : total - 1;
+        e_ok[q] = idx < total;
+        e_row[q] = idc >> qshift;
+        e_col[q] = cur.grp0 * gw + ((idc & ((1 << qshift) - 1)) << 2);
+        const int colc = e_col[q] < g_Npad - 4 ? e_col[q] : g_Npad - 4;
+        const float* pb = g_bias + colc; const float* ps = g_gn_s + (long long)e_row[q] * g_rowstride + colc; const float* pg = g_gn_b1 + (long long)e_row[q] * g_rowstride + colc;
+        if (q == 0) PIX_ELOAD(pb, ps, pg, 64, 67, 68, 71, 72, 75); else PIX_ELOAD(pb, ps, pg, 76, 79, 80, 83, 84, 87);
+      }
+      PSTAMP(0);
+      f32x4p acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const int nu = cur.nkp / PD;
+      if (!small) {
+        const int n = lane & 15, g = lane >> 4;
+        int rs = rtab[((asel[0] >> 16) & 0x7fff) * 16 + n];
+        const float* ap0 = lds + (asel[0] & 0xffff) + rs * 16 + 4 * g;
+        f32x4p a0 = *reinterpret_cast<const f32x4p*>(ap0), a1 = *reinterpret_cast<const f32x4p*>(ap0 + PCS);
+        if (scale2 && (asel[0] >> 31)) { a0 *= inv_r; a1 *= inv_r; }
+        rs = rtab[((asel[1] >> 16) & 0x7fff) * 16 + n];
+        for (int u = 0; u < nu; ++u) {
+          const bool last = u == nu - 1;
+          const PixStep* lst = last ? st_n : st_c + (u + 1) * PD;
+          const unsigned loff = last ? off_n : off_c;
+#pragma unroll
+          for (int r = 0; r < PD; ++r) {
+            // A operands of the NEXT step (its row was selected one step ago), row selector of the step after it
+            const unsigned an = asel[(r + 1) % PD];
+            const float* apn = lds + (an & 0xffff) + rs * 16 + 4 * g;
+            f32x4p n0 = *reinterpret_cast<const f32x4p*>(apn), n1 = *reinterpret_cast<const f32x4p*>(apn + PCS);
+            if (scale2 && (an >> 31)) { n0 *= inv_r; n1 *= inv_r; }
+            const PixStep e = ldc_step(lst + r);
+            PIX_MFMA16_SLOT(r, a0, a1);
+            asel[r] = e.a_sel;
+            rs = rtab[((asel[(r + 2) % PD] >> 16) & 0x7fff) * 16 + n];
+            const float* base_ = frag + e.w_off;
+            PIX_LOAD_SLOT(r, base_, loff);
+            a0 = n0; a1 = n1;
+          }
+        }
+      } else {
+        const int ri = lane & 3;
+        int rs = rtab[((asel[0] >> 16) & 0x7fff) * 16 + ri];
+        const float* ap0 = lds + (asel[0] & 0xffff) + rs * 16;
+        f32x4p q0 = *reinterpret_cast<const f32x4p*>(ap0), q1 = *reinterpret_cast<const f32x4p*>(ap0 + 4), q2 = *reinterpret_cast<const f32x4p*>(ap0 + 8), q3 = *reinterpret_cast<const f32x4p*>(ap0 + 12);
+        if (scale2 && (asel[0] >> 31)) { q0 *= inv_r; q1 *= inv_r; q2 *= inv_r; q3 *= inv_r; }
+        rs = rtab[((asel[1] >> 16) & 0x7fff) * 16 + ri];
+        for (int u = 0; u < nu; ++u) {
+          const bool last = u == nu - 1;
+          const PixStep* lst = last ? st_n : st_c + (u + 1) * PD;
+          const unsigned loff = last ? off_n : off_c;
+#pragma unroll
+          for (int r = 0; r < PD; ++r) {
+            const unsigned an = asel[(r + 1) % PD];
+            const float* apn = lds + (an & 0xffff) + rs * 16;
+            f32x4p n0 = *reinterpret_cast<const f32x4p*>(apn), n1 = *reinterpret_cast<const f32x4p*>(apn + 4), n2 = *reinterpret_cast<const f32x4p*>(apn + 8), n3 = *reinterpret_cast<const f32x4p*>(apn + 12);
+            if (scale2 && (an >> 31)) { n0 *= inv_r; n1 *= inv_r; n2 *= inv_r; n3 *= inv_r; }
+            const PixStep e = ldc_step(lst + r);
+            PIX_MFMA4_SLOT(r);
+            asel[r] = e.a_sel;
+            rs = rtab[((asel[(r + 2) % PD] >> 16) & 0x7fff) * 16 + ri];
+            const float* base_ = frag + e.w_off;
+            PIX_LOAD_SLOT(r, base_, loff);
+            q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+          }
         }
       }
-      f32x4p acc[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = f32x4p{0.f, 0.f, 0.f, 0.f};
-      // chunks of this wave in this pass (all source-1 taps have the same depth: no walk over the tap table here)
-      const int nk = op.k_ntap1 * (op.k_nch1 > wk ? (op.k_nch1 - wk + ksplit - 1) >> ksh : 0) + (op.k_nch2 > wk ? (op.k_nch2 - wk + ksplit - 1) >> ksh : 0);
-      // Two cursors walk this wave's chunk list (tap by tap, chunks wk, wk + ksplit, ... of each): L issues the weight loads P_RING chunks
-      // ahead of C, which consumes them.  Per chunk a cursor costs one pointer increment; the tap's fields are read from LDS once per tap.
-      struct CurL { const float* w; int left, t; };
-      struct CurC { int a, stepa, left, t, src2; };
-      const long long wstep = (long long)ksplit * 16 * npad;
-      auto next_l = [&](CurL& u) {
-        for (;;) {
-          ++u.t;
-          if (u.t >= ntap) { u.left = 1 << 30; u.w = op.Wt; return; }     // cannot happen (nk counts exactly the chunks below): never walk off the table
-          const int* tp = tapl + u.t * P_TAP_I;
-          const int nch = __builtin_amdgcn_readfirstlane(tp[3]);
-          if (nch <= wk) continue;                         // this wave has no chunk of that tap
-          u.left = (nch - wk + ksplit - 1) >> ksh;
-          u.w = (__builtin_amdgcn_readfirstlane(tp[4]) ? op.Wt2 : op.Wt) + __builtin_amdgcn_readfirstlane(tp[0]) + (long long)(16 * wk + g) * npad + col;
-          return;
-        }
-      };
-      auto next_c = [&](CurC& u) {
-        for (;;) {
-          ++u.t;
-          if (u.t >= ntap) { u.left = 1 << 30; u.a = act_floats; u.stepa = 0; u.src2 = 0; return; }
-          const int* tp = tapl + u.t * P_TAP_I;
-          const int nch = __builtin_amdgcn_readfirstlane(tp[3]);
-          if (nch <= wk) continue;
-          u.left = (nch - wk + ksplit - 1) >> ksh;
-          u.src2 = __builtin_amdgcn_readfirstlane(tp[4]);
-          const int srow = sbyte(tp + 8, small ? (lane & 3) : q);
-          const int acs = __builtin_amdgcn_readfirstlane(tp[2]);
-          if (srow >= 0) { u.a = __builtin_amdgcn_readfirstlane(tp[1]) + srow * 16 + g * 4 + wk * acs; u.stepa = ksplit * acs; }
-          else { u.a = act_floats + g * 4; u.stepa = 0; }
-          return;
-        }
-      };
-      CurL L{nullptr, 0, -1};
-      CurC C{0, 0, 0, -1, 0};
-      f32x4p ring[P_RING][4];
-      auto issue = [&](f32x4p* r) {
-        if (L.left == 0) next_l(L);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = *(const gf32x4p*)(unsigned long long)(L.w + (long long)(4 * j) * npad);
-        L.w += wstep; --L.left;
-      };
-      auto consume = [&](const f32x4p* r) {
-        if (C.left == 0) next_c(C);
-        float4 a = *reinterpret_cast<const float4*>(lds + C.a);
-        C.a += C.stepa; --C.left;
-        if (gn && C.src2) { a.x *= inv_r; a.y *= inv_r; a.z *= inv_r; a.w *= inv_r; }
-        const float av[4] = {a.x, a.y, a.z, a.w};
-        if (small) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[j], r[j][i], acc[i], 0, 0, 0);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], r[j][i], acc[i], 0, 0, 0);
-        }
-      };
-#pragma unroll
-      for (int r = 0; r < P_RING; ++r) if (r < nk) issue(ring[r]);
+      asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc0), "+v"(acc1));      // MFMA results -> VALU / LDS readers (hipcc pads nothing behind an asm MFMA)
       PSTAMP(1);
-      for (int i = 0; i < nk; i += P_RING) {
+      // partial tiles -> LDS.  16-row path: lane (n, g) holds rows 4 g + v of columns n (acc0) and 16 + n (acc1); 4-row path: row v of column `lane`
+      if (!small) {
+        const int n = lane & 15, g = lane >> 4;
 #pragma unroll
-        for (int r = 0; r < P_RING; ++r) {
-          if (i + r < nk) {
-            consume(ring[r]);
-            if (i + r + P_RING < nk) issue(ring[r]);
-          }
-        }
-      }
-      PSTAMP(2);
-      // L2 warm-up for the next GEMM: its ring fill would otherwise be a chip-wide first touch on this op's critical path; the touches
-      // fly under the reduction and the epilogue below (results only feed `sink`)
-      float pf0 = 0.f, pf1 = 0.f;
-      if (cb0 + par >= nb && op.pf_ptr) {
-        if (tid < op.pf_lines) pf0 = op.pf_ptr[(long long)tid * 32];
-        if (tid + PNT < op.pf_lines) pf1 = op.pf_ptr[(long long)(tid + PNT) * 32];
-      }
-      // partials: red[wave][row 4 g + v][column 4 q + i]
+        for (int v = 0; v < 4; ++v) { red[wave * 512 + (4 * g + v) * 32 + n] = acc0[v]; red[wave * 512 + (4 * g + v) * 32 + 16 + n] = acc1[v]; }
+      } else {
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
-        *reinterpret_cast<float4*>(red + (wave * 16 + 4 * g + v) * 64 + 4 * q) = make_float4(acc[0][v], acc[1][v], acc[2][v], acc[3][v]);
+        for (int v = 0; v < 4; ++v) red[wave * 512 + v * 64 + lane] = acc0[v] + acc1[v];
+      }
       __syncthreads();
-      PSTAMP(3);
+      PSTAMP(2);
+      // epilogue: operands out of the AGPRs (everything but the 16 loads just issued for the next item has landed)
+      {
+        f32x4p eb[2], es[2], eg[2];
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        PIX_EREAD4(eb[0], 64, 65, 66, 67); PIX_EREAD4(es[0], 68, 69, 70, 71); PIX_EREAD4(eg[0], 72, 73, 74, 75);
+        PIX_EREAD4(eb[1], 76, 77, 78, 79); PIX_EREAD4(es[1], 80, 81, 82, 83); PIX_EREAD4(eg[1], 84, 85, 86, 87);
+        const int groups = 1 << cur.gshift, ksplit = 1 << cur.kshift;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (j < par) {
-        const int n = (cb0 + j) * 64 + ec2;
-        float t0 = 0.f, t1 = 0.f;
-        if (small) {                                     // rows 4 gg + erow of a wave's slab are the four k groups' partials of row erow
-          if (erow < 4)
-            for (int w = 0; w < ksplit; ++w)
+        for (int q = 0; q < 2; ++q) {
+          const int row = e_row[q], col = e_col[q];
+          const int cw = col - cur.grp0 * gw, grp = small ? cw >> 6 : cw >> 5, sub = cw & (gw - 1);
+          f32x4p t = {0.f, 0.f, 0.f, 0.f};
+          for (int sl = 0; sl < ksplit; ++sl) t += *reinterpret_cast<const f32x4p*>(red + (sl * groups + grp) * 512 + row * gw + sub);
+          const bool ok = e_ok[q] && col < g_nstore;
+          f32x4p o = {0.f, 0.f, 0.f, 0.f};
+          if (ok) {
+            if (gn) t = t * rstd + (eg[q] - (mean * rstd) * es[q]);
+            t += eb[q];
+            if (g_res_lds >= 0) t += *reinterpret_cast<const f32x4p*>(lds + g_res_lds + pix_at(col, sbyte(g_res_row, row)));
 #pragma unroll
-              for (int gg = 0; gg < 4; ++gg) { const float2 v = *reinterpret_cast<const float2*>(red + ((j * ksplit + w) * 16 + 4 * gg + erow) * 64 + ec2); t0 += v.x; t1 += v.y; }
-        } else {
-          for (int w = 0; w < ksplit; ++w) { const float2 v = *reinterpret_cast<const float2*>(red + ((j * ksplit + w) * 16 + erow) * 64 + ec2); t0 += v.x; t1 += v.y; }
-        }
-        const bool ok = n < op.nstore && erow < op.P_out;
-        float o0 = 0.f, o1 = 0.f;
-        if (ok) {
-          if (gn) { t0 = t0 * rstd + (e_g[j].x - (mean * rstd) * e_s[j].x); t1 = t1 * rstd + (e_g[j].y - (mean * rstd) * e_s[j].y); }
-          t0 += e_b[j].x; t1 += e_b[j].y;
-          if (op.res_lds >= 0) {
-            t0 += lds[op.res_lds + pix_at(n, rrow, op.res_cs)]; t1 += lds[op.res_lds + pix_at(n + 1, rrow, op.res_cs)];
+            for (int e = 0; e < 4; ++e) o[e] = pix_act(g_act, t[e]);
+            if (g_out_lds >= 0) *reinterpret_cast<f32x4p*>(lds + g_out_lds + pix_at(col, row)) = o;
+            if (g_out_g) *reinterpret_cast<f32x4p*>(g_out_g + ((long long)row * B + b) * g_ldo + col) = o;
+            sacc += o[0] + o[1] + o[2] + o[3]; qacc += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
           }
-          o0 = pix_act(op.act, t0); o1 = pix_act(op.act, t1);
-          if (op.out_lds >= 0) { lds[op.out_lds + pix_at(n, erow, op.out_cs)] = o0; lds[op.out_lds + pix_at(n + 1, erow, op.out_cs)] = o1; }
-          if (op.out_g) *reinterpret_cast<float2*>(op.out_g + ((long long)erow * B + b) * op.ldo + n) = make_float2(o0, o1);
-          sacc += o0 + o1; qacc += o0 * o0 + o1 * o1;
-        }
-        if (op.stat_g) {                                  // the plan's partial layout: one (sum, sumsq) per (pixel, 32-column block)
-          float s32 = o0 + o1, q32 = o0 * o0 + o1 * o1;
+          if (g_stat_g) {                                  // the plan's partial layout: one (sum, sumsq) per (pixel, 32-column block) = 8 consecutive threads
+            float s32 = o[0] + o[1] + o[2] + o[3], q32 = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
 #pragma unroll
-          for (int m = 1; m < 16; m <<= 1) { s32 += __shfl_xor(s32, m); q32 += __shfl_xor(q32, m); }
-          const int nbk = n >> 5;
-          if ((tid & 15) == 0 && nbk < op.nblk && erow < op.P_out) op.stat_g[((long long)erow * op.nblk + nbk) * B + b] = make_float2(s32, q32);
-        }
+            for (int m = 1; m < 8; m <<= 1) { s32 += __shfl_xor(s32, m); q32 += __shfl_xor(q32, m); }
+            const int nbk = col >> 5;
+            if ((tid & 7) == 0 && e_ok[q] && nbk < g_nblk) g_stat_g[((long long)row * g_nblk + nbk) * B + b] = make_float2(s32, q32);
+          }
         }
       }
-      __syncthreads();                                    // red (and the taps, after the last pass) are reused
-      PSTAMP(4);
-      sink ^= __float_as_uint(pf0) ^ __float_as_uint(pf1);
-      cb0 += par;
+      __syncthreads();                                    // red is reused; the output slab is complete
+      PSTAMP(3);
+      cur = nxt; off_c = off_n; st_c = st_n; ci = ni;
     }
-    if (op.stat_out >= 0) {
+    if (g_stat_out >= 0) {
       float ss = sacc, q2 = qacc;
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) { ss += __shfl_xor(ss, m); q2 += __shfl_xor(q2, m); }
@@ -401,45 +489,121 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       if (tid == 0) {
         float a0 = 0.f, a1 = 0.f;
         for (int w = 0; w < PNW; ++w) { a0 += scr[w]; a1 += scr[PNW + w]; }
-        stat[op.stat_out * 2] = a0; stat[op.stat_out * 2 + 1] = a1;
+        stat[g_stat_out * 2] = a0; stat[g_stat_out * 2 + 1] = a1;
       }
       __syncthreads();
     }
   }
+  // the loads issued for the wrapped-around "next" item must land before the wave ends
+  asm volatile("s_waitcnt vmcnt(0)" ::: PIX_CLOB_0, PIX_CLOB_1, PIX_CLOB_2, PIX_CLOB_3, PIX_CLOB_E);
   if (dbg && b == 0 && tid == 0) dbg[count] = __builtin_amdgcn_s_memtime();
-  if (sink == 0x9e3779b9u && dbg) dbg[255] = 1;          // consumes the warm-up touches
 }
 
 // ------------------------------------------------------------------------------------------------
-// host: build the program of one run of chain-level ops, launch it
+// host: fragment-order weights (once per model), programs of op runs (per run, on demand), launch
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-struct PSlot { long long base; int ld; int P; int rows; int lds; int t0, t1; };
+struct PSlot { long long base; int ld; int P; int lds; int t0, t1; };
 
-int rows_of(int P) { return P <= 16 ? 16 : (P + 15) / 16 * 16; }
 void set_sbyte(int* w, int r, int v) { w[r >> 2] = (w[r >> 2] & ~(0xff << (8 * (r & 3)))) | ((v & 0xff) << (8 * (r & 3))); }
 
+struct PFragOp {                          // fragment-order copy of one GEMM op's weights
+  bool small = false;
+  long long off = 0;                      // float offset in the fragment arena
+  int F = 0;                              // steps per column group: live taps x K steps (+ source 2)
+  int groups = 0;                         // column groups (32 or 64 columns)
+  std::vector<int> taps;                  // live taps (ky * KW + kx), in step order
+  int ndc = 0, ndc2 = 0;                  // K steps per tap / of source 2
+};
+
+struct PProgram { PixOpD* d_ops = nullptr; PixItem* d_items = nullptr; PixStep* d_steps = nullptr; unsigned char* d_rowtab = nullptr;
+                  int n_ops = 0, n_items = 0, n_rowtab = 0, act_floats = 0; std::vector<int> kinds; };
+
+}  // namespace
+
+struct PixState {
+  float* d_frag = nullptr; size_t frag_floats = 0;
+  std::map<int, PFragOp> fops;            // by plan op index
+  std::map<long long, PProgram> programs; // by first * 4096 + count
+  std::mutex mu;                          // programs are built on demand (debug sub-ranges); one handle may be driven from several host threads in the tests
+  const float* zero4 = nullptr;           // 4+ zero floats in the params arena
+};
+
+namespace {
+
+bool pix_tap_live(const GemmOp& g, int ky, int kx) {
+  const int P_out = g.Hout * g.Wout;
+  for (int r = 0; r < P_out; ++r)
+    if (tap_source_pixel(r / g.Wout, r % g.Wout, ky, kx, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W) >= 0) return true;
+  return false;
+}
+
+const char* pix_gemm_supported(const GemmOp& g) {
+  const int P_out = g.Hout * g.Wout, P_in = g.a.H * g.a.W;
+  if (P_out > 16 || P_in > 16 || g.a_ext || g.out_nchw || g.w_pix_stride || g.bias_pix_stride || g.a_bcast || g.a_rows) return "pixel kernel: unsupported GEMM op";
+  if ((g.Kp & 31) || (g.has2 && (g.Kp2 & 31)) || (g.Npad & 31) || (g.out.C & 3)) return "pixel kernel: K and N must be multiples of 32";
+  if (g.has2 && g.a2.H * g.a2.W > 16) return "pixel kernel: source 2 has more than 16 pixels";
+  return nullptr;
+}
+
+// [tap][Npad][Kp] (+ [Npad][Kp2]) -> fragment order.  16-row path: block (pair tp, step f) = [half h][tile t][lane][4] =
+// W[n = 32 tp + 16 t + (lane & 15)][k = 32 dc + 16 h + 4 (lane >> 4) + i]; 4-row path: block (tile tl, step f) = [k group j][lane][4] =
+// W[n = 64 tl + lane][k = 16 dc + 4 j + i].  Only taps that reach at least one output pixel are packed.
+void pack_fragments(const float* prm, const GemmOp& g, PFragOp* fo, std::vector<float>* arena) {
+  const int P_out = g.Hout * g.Wout;
+  fo->small = P_out <= 4;
+  const int kstep = fo->small ? 16 : 32, gw = fo->small ? 64 : 32;
+  fo->ndc = g.Kp / kstep; fo->ndc2 = g.has2 ? g.Kp2 / kstep : 0;
+  fo->taps.clear();
+  for (int ky = 0; ky < g.KH; ++ky) for (int kx = 0; kx < g.KW; ++kx) if (pix_tap_live(g, ky, kx)) fo->taps.push_back(ky * g.KW + kx);
+  fo->F = (int)fo->taps.size() * fo->ndc + fo->ndc2;
+  fo->groups = (g.Npad + gw - 1) / gw;
+  fo->off = (long long)arena->size();
+  arena->resize(arena->size() + (size_t)fo->groups * fo->F * 1024, 0.f);
+  float* dst = arena->data() + fo->off;
+  for (int gi = 0; gi < fo->groups; ++gi)
+    for (int f = 0; f < fo->F; ++f) {
+      const bool s2 = f >= (int)fo->taps.size() * fo->ndc;
+      const int tap = s2 ? 0 : fo->taps[f / fo->ndc], dc = s2 ? f - (int)fo->taps.size() * fo->ndc : f % fo->ndc;
+      const float* W = s2 ? prm + g.w2_off : prm + g.w_off + (long long)tap * g.Npad * g.Kp;
+      const int Kp = s2 ? g.Kp2 : g.Kp;
+      float* blk = dst + ((size_t)gi * fo->F + f) * 1024;
+      if (!fo->small) {
+        for (int h = 0; h < 2; ++h) for (int t = 0; t < 2; ++t) for (int lane = 0; lane < 64; ++lane) {
+          const int n = 32 * gi + 16 * t + (lane & 15), k = 32 * dc + 16 * h + 4 * (lane >> 4);
+          if (n < g.Npad) std::memcpy(blk + ((h * 2 + t) * 64 + lane) * 4, W + (long long)n * Kp + k, 16);
+        }
+      } else {
+        for (int j = 0; j < 4; ++j) for (int lane = 0; lane < 64; ++lane) {
+          const int n = 64 * gi + lane, k = 16 * dc + 4 * j;
+          if (n < g.Npad) std::memcpy(blk + (j * 64 + lane) * 4, W + (long long)n * Kp + k, 16);
+        }
+      }
+    }
+}
+
 struct PBuilder {
-  const Plan& plan; const DevPlan& dp; int first, count;
-  std::vector<PSlot> slots; int act_floats = 0;
-  std::vector<PixOpD> ops; std::vector<PixTap> taps;
+  const Plan& plan; const DevPlan& dp; const PixState& st; int first, count;
+  std::vector<PSlot> slots; int act_chunks = 0;
+  std::vector<PixOpD> ops; std::vector<PixItem> items; std::vector<PixStep> steps; std::vector<unsigned char> rowtab;
   std::map<long long, int> stat_of;
   std::map<int, int> produced;
   const std::vector<PSlot>* preset = nullptr;
   std::vector<int> touched;
   const char* err = nullptr;
 
-  // LDS float offset of (row 0, channel 0 of the view) and the slab's chunk stride
-  int slab(const View& v, int* cs, int* slot_index) {
+  static int chunks_of(int ld) { return (ld + 15) / 16 + 1; }     // + one chunk of slack: K is walked to the weights' padded depth
+  // LDS float offset of (row 0, channel 0 of the view)
+  int slab(const View& v, int* slot_index) {
     const int P = v.H * v.W;
     for (size_t i = 0; i < slots.size(); ++i) {
       PSlot& s = slots[i];
       if (s.ld == v.ld && s.P == P && v.off >= s.base && v.off < s.base + s.ld) {
-        *cs = s.rows * 16; if (slot_index) *slot_index = (int)i;
+        if (slot_index) *slot_index = (int)i;
         touched.push_back((int)i);
         if ((v.off - s.base) & 15) err = "pixel kernel: a view does not start on a 16-channel boundary";
-        return s.lds + (int)((v.off - s.base) >> 4) * s.rows * 16;
+        return s.lds + (int)((v.off - s.base) >> 4) * PCS;
       }
     }
     long long base = v.off;
@@ -451,29 +615,29 @@ struct PBuilder {
       else if (o.kind == OP_GN_RES) { look(o.gr.u); look(o.gr.x); look(o.gr.out); }
       else if (o.kind == OP_LINATTN) { look(o.at.qkv); look(o.at.out); }
     }
-    PSlot s{base, v.ld, P, rows_of(P), act_floats, (int)ops.size(), (int)ops.size()};
+    PSlot s{base, v.ld, P, act_chunks * PCS, (int)ops.size(), (int)ops.size()};
     if (v.ld & 15) err = "pixel kernel: a tensor's channel pitch is not a multiple of 16";
     if (preset) {
       for (const PSlot& ps : *preset) if (ps.base == base && ps.ld == v.ld && ps.P == P) s.lds = ps.lds;
     } else {
-      act_floats += s.rows * s.ld;
+      act_chunks += chunks_of(s.ld);
     }
     slots.push_back(s);
     touched.push_back((int)slots.size() - 1);
-    *cs = s.rows * 16; if (slot_index) *slot_index = (int)slots.size() - 1;
+    if (slot_index) *slot_index = (int)slots.size() - 1;
     if ((v.off - s.base) & 15) err = "pixel kernel: a view does not start on a 16-channel boundary";
-    return s.lds + (int)((v.off - s.base) >> 4) * s.rows * 16;
+    return s.lds + (int)((v.off - s.base) >> 4) * PCS;
+  }
+  PixOpD stage_op(const PSlot& s) {
+    PixOpD d{}; d.kind = PIX_STAGE;
+    d.st_src = dp.ws + s.base; d.st_ld = s.ld; d.st_C = s.ld; d.st_P = s.P; d.st_lds = s.lds; d.st_stat = -1;
+    return d;
   }
   // An op that writes only PART of a buffer (one half of a skip concatenation) while the rest was produced outside the run: the whole
   // buffer is staged first, so that later readers of the full width find the other half.
   void mark_produced(const View& v) {
-    int cs, si; slab(v, &cs, &si);
-    if (!produced.count(si) && (v.off != slots[si].base || v.C < slots[si].ld)) {
-      PixOpD st{}; st.kind = PIX_STAGE;
-      const PSlot& s = slots[si];
-      st.st_src = dp.ws + s.base; st.st_ld = s.ld; st.st_C = s.ld; st.st_P = s.P; st.st_lds = s.lds; st.st_cs = s.rows * 16; st.st_stat = -1;
-      ops.push_back(st);
-    }
+    int si; slab(v, &si);
+    if (!produced.count(si) && (v.off != slots[si].base || v.C < slots[si].ld)) ops.push_back(stage_op(slots[si]));
     produced[si] = 1;
   }
   int stat_slot(long long off) {
@@ -483,97 +647,125 @@ struct PBuilder {
     stat_of[off] = s;
     return s;
   }
-  int need(const View& v, int* cs, long long stat_off = -1, int nparts = 0) {
-    int si; const int off = slab(v, cs, &si);
+  int need(const View& v, long long stat_off = -1, int nparts = 0) {
+    int si; const int off = slab(v, &si);
     const bool have_stat = stat_off < 0 || stat_of.count(stat_off);
     if (produced.count(si) && have_stat) return off;
-    PixOpD st{}; st.kind = PIX_STAGE;
-    const PSlot& s = slots[si];
-    st.st_src = dp.ws + s.base; st.st_ld = s.ld; st.st_C = s.ld; st.st_P = s.P; st.st_lds = s.lds; st.st_cs = s.rows * 16; st.st_stat = -1;
-    if (produced.count(si)) st.st_P = 0;
+    PixOpD d = stage_op(slots[si]);
+    if (produced.count(si)) d.st_P = 0;
     if (stat_off >= 0 && !stat_of.count(stat_off)) {
-      st.st_stat = stat_slot(stat_off); st.st_part = reinterpret_cast<const float2*>(dp.ws + stat_off); st.st_nparts = nparts;
+      d.st_stat = stat_slot(stat_off); d.st_part = reinterpret_cast<const float2*>(dp.ws + stat_off); d.st_nparts = nparts;
     }
-    ops.push_back(st);
+    ops.push_back(d);
     produced[si] = 1;
     return off;
   }
+  int add_rowtab(const int* rows16) {
+    const int idx = (int)rowtab.size() / 16;
+    for (int r = 0; r < 16; ++r) rowtab.push_back((unsigned char)(rows16[r] < 0 ? 16 : rows16[r]));
+    return idx;
+  }
 };
 
-struct PProgram { PixOpD* d_ops = nullptr; PixTap* d_taps = nullptr; int n_ops = 0; int act_floats = 0; int ntaps = 0; };
-std::map<std::pair<const void*, long long>, PProgram> g_pprograms;
+size_t pix_lds_bytes(int act_floats, int nrowtab) { return sizeof(float) * ((size_t)act_floats + P_RED_F + P_STAT_SLOTS * 2 + P_SCR_F) + (size_t)nrowtab * 16 + 16; }
 
-size_t pix_lds_bytes(int act_floats, int ntaps) { return sizeof(float) * ((size_t)act_floats + P_ZERO_F + P_RED_F + P_STAT_SLOTS * 2 + P_SCR_F) + sizeof(int) * (size_t)(ntaps + 1) * P_TAP_I; }
-
-const char* pixrun_build(const DevPlan& dp, int first, int count) {
+const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, PProgram* out) {
   const Plan& plan = *dp.plan;
-  const auto key = std::make_pair((const void*)&plan, (long long)first * 4096 + count);
-  if (g_pprograms.count(key)) return nullptr;
   auto fill = [&](PBuilder& b) -> const char* {
+    b.rowtab.assign(16, 16);                              // table 0: every row -> the zero row (no-op steps)
     for (int i = first; i < first + count; ++i) {
       const Op& op = plan.ops[i];
       b.touched.clear();
       PixOpD d{};
       d.kind = op.kind; d.gn_stat = -1; d.stat_out = -1; d.out_lds = -1; d.res_lds = -1; d.in_lds = -1;
+      d.bias = d.gn_s = d.gn_b1 = st.zero4;
       if (op.kind == OP_DWCONV7) {
         const DwOp& o = op.dw;
-        if (o.in.H > 4 || o.in.W > 4 || (PNT % o.in.C) || o.in.C > PNT) return "pixel kernel: depth-wise op outside the supported shapes";
-        d.in_lds = b.need(o.in, &d.in_cs);
-        d.out_lds = b.slab(o.out, &d.out_cs, nullptr); b.mark_produced(o.out);
+        if (o.in.H > 4 || o.in.W > 4 || o.stat_slabs > 1) return "pixel kernel: depth-wise op outside the supported shapes";
+        d.in_lds = b.need(o.in);
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out);
         d.dw = make_dw_args(plan, o, dp.prm, dp.ws, dp.ctl);
         if (o.stat_off >= 0) d.stat_out = b.stat_slot(o.stat_off);
       } else if (op.kind == OP_GN_RES) {
         const GnResOp& o = op.gr;
-        if (o.u.H * o.u.W > 16 || o.out_ext) return "pixel kernel: unsupported GroupNorm+residual op";
-        d.in_lds = b.need(o.u, &d.in_cs, o.part_off, o.nparts);
-        d.x_lds = b.need(o.x, &d.x_cs);
+        if (o.u.H * o.u.W > 16 || o.out_ext || (o.u.C & 3)) return "pixel kernel: unsupported GroupNorm+residual op";
+        d.in_lds = b.need(o.u, o.part_off, o.nparts);
+        d.x_lds = b.need(o.x);
         d.gn_stat = b.stat_slot(o.part_off);
-        d.out_lds = b.slab(o.out, &d.out_cs, nullptr); b.mark_produced(o.out);
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out);
         d.gr = make_gnres_args(o, dp.prm, dp.ws);
       } else if (op.kind == OP_LINATTN) {
         const AttnOp& o = op.at;
         if (o.qkv.H * o.qkv.W > 16 || o.dh != 32 || o.heads * 32 > 256 || o.heads * 32 * 33 > P_SCR_F) return "pixel kernel: unsupported attention op";
-        d.in_lds = b.need(o.qkv, &d.in_cs);
-        d.out_lds = b.slab(o.out, &d.out_cs, nullptr); b.mark_produced(o.out);
+        d.in_lds = b.need(o.qkv);
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out);
         d.at = make_attn_args(o, dp.ws);
       } else if (op.kind == OP_GEMM) {
         const GemmOp& g = op.g;
-        const int P_out = g.Hout * g.Wout, P_in = g.a.H * g.a.W;
-        if (P_out > 16 || P_in > 64 || g.a_ext || g.out_nchw || g.w_pix_stride || g.bias_pix_stride || g.a_bcast || g.a_rows || g.wt_off < 0) return "pixel kernel: unsupported GEMM op";
-        if ((g.Kp & 15) || (g.has2 && (g.Kp2 & 15)) || (g.Npad & 3) || (g.out.C & 1)) return "pixel kernel: K must be a multiple of 16";
-        int acs; const int a_lds = b.need(g.a, &acs, g.gn ? g.gn_part_off : -1, g.gn_nparts);
-        int a2cs = 0, a2_lds = -1;
-        if (g.has2) a2_lds = b.need(g.a2, &a2cs);
-        if (g.has_res) d.res_lds = b.need(g.r, &d.res_cs);
+        if (const char* e = pix_gemm_supported(g)) return e;
+        auto fit = st.fops.find(i);
+        if (fit == st.fops.end()) return "pixel kernel: no fragment-order weights for this op";
+        const PFragOp& fo = fit->second;
+        const int P_out = g.Hout * g.Wout;
+        const int a_lds = b.need(g.a, g.gn ? g.gn_part_off : -1, g.gn_nparts);
+        int a2_lds = -1;
+        if (g.has2) a2_lds = b.need(g.a2);
+        if (g.has_res) d.res_lds = b.need(g.r);
         d.P_out = P_out; d.Npad = g.Npad; d.nstore = g.out.C; d.act = g.act; d.ldo = g.out.ld;
-        d.Wt = dp.prm + g.wt_off; d.Wt2 = g.has2 ? dp.prm + g.wt2_off : nullptr;
-        d.bias = g.bias_off >= 0 ? dp.prm + g.bias_off : nullptr;
-        if (g.gn) { d.gn_stat = b.stat_slot(g.gn_part_off); d.gn_inv = g.gn_inv_count; d.gn_s = dp.prm + g.gn_s_off; d.gn_b1 = dp.prm + g.gn_b1_off; }
+        if (g.bias_off >= 0) d.bias = dp.prm + g.bias_off;
+        if (g.gn) { d.gn_stat = b.stat_slot(g.gn_part_off); d.gn_inv = g.gn_inv_count; d.gn_s = dp.prm + g.gn_s_off; d.gn_b1 = dp.prm + g.gn_b1_off; d.gn_rowstride = g.Npad; }
+        d.scale2 = (g.gn && g.has2) ? 1 : 0;
         d.out_g = dp.ws + g.out.off;
-        d.out_lds = b.slab(g.out, &d.out_cs, nullptr); b.mark_produced(g.out);
+        d.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out);
         if (g.stat_off >= 0) { d.stat_out = b.stat_slot(g.stat_off); d.stat_g = reinterpret_cast<float2*>(dp.ws + g.stat_off); d.nblk = (g.out.C + 31) / 32; }
-        d.tap_first = (int)b.taps.size();
+        // row tables: one per live tap (+ source 2)
         const int w2 = g.has2 ? g.a2.W : (g.has_res ? g.r.W : 1);
-        for (int ky = 0; ky < g.KH; ++ky) for (int kx = 0; kx < g.KW; ++kx) {
-          PixTap t{}; t.w_off = (int)((long long)(ky * g.KW + kx) * g.Kp * g.Npad); t.a_lds = a_lds; t.a_cs = acs; t.nch = g.Kp / 16; t.src2 = 0;
-          bool any = false;
-          for (int r = 0; r < 16; ++r) {
-            int qp = -1;
-            if (r < P_out) qp = tap_source_pixel(r / g.Wout, r % g.Wout, ky, kx, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W);
-            set_sbyte(t.src, r, qp);
-            any |= qp >= 0;
-          }
-          if (any) b.taps.push_back(t);
+        std::vector<int> tab_of;
+        for (int tp : fo.taps) {
+          int rows[16];
+          for (int r = 0; r < 16; ++r) rows[r] = r < P_out ? tap_source_pixel(r / g.Wout, r % g.Wout, tp / g.KW, tp % g.KW, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W) : -1;
+          tab_of.push_back(b.add_rowtab(rows));
         }
-        for (int r = 0; r < 16; ++r) set_sbyte(d.res_row, r, r < P_out ? ((r / g.Wout) / g.up2) * w2 + ((r % g.Wout) / g.up2) : 0);
-        if (g.has2) {
-          PixTap t{}; t.w_off = 0; t.a_lds = a2_lds; t.a_cs = a2cs; t.nch = g.Kp2 / 16; t.src2 = 1;
-          for (int r = 0; r < 16; ++r) set_sbyte(t.src, r, r < P_out ? ((r / g.Wout) / g.up2) * w2 + ((r % g.Wout) / g.up2) : -1);
-          b.taps.push_back(t);
+        int tab2 = 0;
+        {
+          int rows[16];
+          for (int r = 0; r < 16; ++r) rows[r] = r < P_out ? ((r / g.Wout) / g.up2) * w2 + ((r % g.Wout) / g.up2) : -1;
+          if (g.has2) tab2 = b.add_rowtab(rows);
+          for (int r = 0; r < 16; ++r) set_sbyte(d.res_row, r, rows[r] < 0 ? 0 : rows[r]);
         }
-        d.tap_cnt = (int)b.taps.size() - d.tap_first;
-        d.k_ntap1 = d.tap_cnt - (g.has2 ? 1 : 0); d.k_nch1 = g.Kp / 16; d.k_nch2 = g.has2 ? g.Kp2 / 16 : 0;
-        if (d.tap_cnt > P_MAXTAP) return "pixel kernel: too many taps";
+        if (b.rowtab.size() / 16 > 0x7fff) return "pixel kernel: too many row tables";
+        // passes and their step tables
+        const int kchunk = fo.small ? 1 : 2;               // LDS chunks per K step
+        d.item0 = (int)b.items.size();
+        for (int g0 = 0; g0 < fo.groups;) {
+          int grp = 1; while (grp * 2 <= PNW && grp * 2 <= fo.groups - g0) grp *= 2;
+          const int ksplit = PNW / grp;
+          const int nk = (fo.F + ksplit - 1) / ksplit, nkp = (nk + PD - 1) / PD * PD;
+          PixItem it{};
+          it.step_base = (int)b.steps.size(); it.nkp = nkp; it.grp0 = g0; it.grp_stride = fo.F * 1024; it.small = fo.small ? 1 : 0;
+          int sh = 0; while ((1 << sh) < grp) ++sh; it.gshift = sh;
+          sh = 0; while ((1 << sh) < ksplit) ++sh; it.kshift = sh;
+          for (int sl = 0; sl < ksplit; ++sl)
+            for (int j = 0; j < nkp; ++j) {
+              const int f = sl + j * ksplit;
+              PixStep e;
+              if (f < fo.F) {
+                const bool s2 = f >= (int)fo.taps.size() * fo.ndc;
+                const int ti = s2 ? 0 : f / fo.ndc, dc = s2 ? f - (int)fo.taps.size() * fo.ndc : f % fo.ndc;
+                const long long aoff = (s2 ? a2_lds : a_lds) + (long long)dc * kchunk * PCS;
+                if (b.preset && aoff > 0xffff) return "pixel kernel: LDS offset out of the step table's range";      // (the first pass lays the slabs out without reuse)
+                e.w_off = (unsigned)(fo.off + ((long long)g0 * fo.F + f) * 1024);
+                e.a_sel = (unsigned)aoff | ((unsigned)(s2 ? tab2 : tab_of[ti]) << 16) | (s2 ? 0x80000000u : 0u);
+              } else {
+                e.w_off = (unsigned)(fo.off + (long long)g0 * fo.F * 1024);
+                e.a_sel = (unsigned)a_lds;                 // row table 0: every row reads zeros
+              }
+              b.steps.push_back(e);
+            }
+          b.items.push_back(it);
+          g0 += grp;
+        }
+        d.nitems = (int)b.items.size() - d.item0;
       } else {
         return "pixel kernel: op kind not supported";
       }
@@ -581,7 +773,6 @@ const char* pixrun_build(const DevPlan& dp, int first, int count) {
       // in this run at all (a debug sub-range).  Statistics likewise.
       {
         auto reads = [&](const Op& o, const View& v) {
-          // same buffer (same pitch and pixel count, origins within one row of each other -- the test PBuilder::slab uses): conservative
           auto hit = [&](const View& w) { return w.ld == v.ld && w.H * w.W == v.H * v.W && w.off - v.off < v.ld && v.off - w.off < v.ld; };
           if (o.kind == OP_GEMM) return hit(o.g.a) || (o.g.has2 && hit(o.g.a2)) || (o.g.has_res && hit(o.g.r));
           if (o.kind == OP_DWCONV7) return hit(o.dw.in);
@@ -608,111 +799,155 @@ const char* pixrun_build(const DevPlan& dp, int first, int count) {
     }
     return nullptr;
   };
-  PBuilder b0{plan, dp, first, count};
+  PBuilder b0{plan, dp, st, first, count};
   if (const char* e = fill(b0)) return e;
+  // pack the slabs by live interval, in whole chunks: every slab starts on a chunk boundary, so row 16 of every chunk position is the
+  // zero row of whichever tensor lives there
   std::vector<PSlot> packed = b0.slots;
+  int top_chunks = 0;
   {
     std::vector<size_t> order(packed.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](size_t x, size_t y) { return packed[x].t0 < packed[y].t0; });
     std::vector<size_t> placed;
-    int top = 0;
     for (size_t oi : order) {
       PSlot& sl = packed[oi];
-      const int size = sl.rows * sl.ld + sl.rows * 16;                 // + one chunk of slack: K is walked to the weights' padded depth
+      const int size = PBuilder::chunks_of(sl.ld);
       int off = 0;
       bool moved = true;
       while (moved) {
         moved = false;
         for (size_t pj : placed) {
           const PSlot& o = packed[pj];
-          const int osize = o.rows * o.ld + o.rows * 16;
+          const int osize = PBuilder::chunks_of(o.ld), ooff = o.lds / PCS;
           const bool live = !(o.t1 < sl.t0 || sl.t1 < o.t0);
-          if (live && off < o.lds + osize && o.lds < off + size) { off = o.lds + osize; moved = true; }
+          if (live && off < ooff + osize && ooff < off + size) { off = ooff + osize; moved = true; }
         }
       }
-      sl.lds = off;
+      sl.lds = off * PCS;
       placed.push_back(oi);
-      top = std::max(top, off + size);
+      top_chunks = std::max(top_chunks, off + size);
     }
-    b0.act_floats = top;
   }
-  PBuilder b{plan, dp, first, count};
-  b.preset = &packed; b.act_floats = b0.act_floats;
+  PBuilder b{plan, dp, st, first, count};
+  b.preset = &packed;
   if (const char* e = fill(b)) return e;
-  for (size_t i = 0; i < b.ops.size(); ++i) {           // warm-up links: a GEMM op names the first tap's weights of the next GEMM op
-    b.ops[i].pf_ptr = nullptr; b.ops[i].pf_lines = 0;
-    if (b.ops[i].kind != OP_GEMM) continue;
-    for (size_t j = i + 1; j < b.ops.size(); ++j) {
-      if (b.ops[j].kind != OP_GEMM) continue;
-      const PixTap& t0 = b.taps[b.ops[j].tap_first];
-      const long long lines = (long long)t0.nch * 16 * b.ops[j].Npad / 32;
-      b.ops[i].pf_ptr = (t0.src2 ? b.ops[j].Wt2 : b.ops[j].Wt) + t0.w_off; b.ops[i].pf_lines = (int)std::min<long long>(lines, 2 * PNT);
-      break;
-    }
-  }
+  const int act_floats = top_chunks * PCS;
   if (b.stat_of.size() > (size_t)P_STAT_SLOTS) return "pixel kernel: too many statistics slots";
-  if (pix_lds_bytes(b.act_floats, (int)b.taps.size()) > 160 * 1024) return "pixel kernel: the activations do not fit the LDS";
+  if (act_floats > 0xffff) return "pixel kernel: the activations exceed the step table's LDS range";
+  if (pix_lds_bytes(act_floats, (int)b.rowtab.size() / 16) > 160 * 1024) return "pixel kernel: the activations do not fit the LDS";
+  if (b.items.empty()) {                                   // a run without a GEMM still needs one (never consumed) item for the loader's prologue
+    PixItem it{}; it.step_base = 0; it.nkp = PD; it.grp_stride = 0;
+    b.items.push_back(it);
+    for (int j = 0; j < PNW * PD; ++j) b.steps.push_back(PixStep{0u, 0u});
+  }
   PProgram p;
-  p.n_ops = (int)b.ops.size(); p.act_floats = b.act_floats; p.ntaps = (int)b.taps.size();
-  if (hipMalloc(&p.d_taps, sizeof(PixTap) * (b.taps.size() + 1)) != hipSuccess) return "pixel kernel: hipMalloc failed";
-  if (hipMemcpy(p.d_taps, b.taps.data(), sizeof(PixTap) * b.taps.size(), hipMemcpyHostToDevice) != hipSuccess) return "pixel kernel: hipMemcpy failed";
-  for (PixOpD& d : b.ops) if (d.kind == OP_GEMM) d.taps = p.d_taps;
-  if (hipMalloc(&p.d_ops, sizeof(PixOpD) * b.ops.size()) != hipSuccess) return "pixel kernel: hipMalloc failed";
-  if (hipMemcpy(p.d_ops, b.ops.data(), sizeof(PixOpD) * b.ops.size(), hipMemcpyHostToDevice) != hipSuccess) return "pixel kernel: hipMemcpy failed";
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pixrun_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
-  g_pprograms.emplace(key, p);
+  p.n_ops = (int)b.ops.size(); p.n_items = (int)b.items.size(); p.n_rowtab = (int)b.rowtab.size() / 16; p.act_floats = act_floats;
+  for (const PixOpD& d : b.ops) p.kinds.push_back(d.kind * 1000 + (d.kind == OP_GEMM ? d.nitems : 0));
+  auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
+    if (hipMalloc(dst, bytes ? bytes : 16) != hipSuccess) return false;
+    return bytes == 0 || hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  if (!up(reinterpret_cast<void**>(&p.d_ops), b.ops.data(), sizeof(PixOpD) * b.ops.size()) ||
+      !up(reinterpret_cast<void**>(&p.d_items), b.items.data(), sizeof(PixItem) * b.items.size()) ||
+      !up(reinterpret_cast<void**>(&p.d_steps), b.steps.data(), sizeof(PixStep) * b.steps.size()) ||
+      !up(reinterpret_cast<void**>(&p.d_rowtab), b.rowtab.data(), b.rowtab.size())) {
+    (void)hipFree(p.d_ops); (void)hipFree(p.d_items); (void)hipFree(p.d_steps); (void)hipFree(p.d_rowtab);
+    return "pixel kernel: device allocation of a program failed";
+  }
+  // the GEMM ops of a run started mid-plan (debug sub-ranges) have no items of their own program before them: nothing to fix up --
+  // item indices are relative to this program's item array
+  *out = p;
   return nullptr;
 }
+
+void free_program(PProgram& p) { (void)hipFree(p.d_ops); (void)hipFree(p.d_items); (void)hipFree(p.d_steps); (void)hipFree(p.d_rowtab); p = PProgram{}; }
 
 }  // namespace
 
 unsigned long long* g_pix_dbg = nullptr;
 
-const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st) {
+// Model creation: fragment-order copies of the weights of every chain-level GEMM op (host params still available), and the programs of
+// every maximal run of such ops.  Any failure leaves the model without a pixel state (the caller falls back to the legacy plan).
+const char* pixrun_prepare(DevPlan& dp, const float* host_params, double* frag_mb) {
   const Plan& plan = *dp.plan;
-  const auto key = std::make_pair((const void*)&plan, (long long)first * 4096 + count);
-  auto it = g_pprograms.find(key);
-  if (it == g_pprograms.end()) {
-    if (const char* e = pixrun_build(dp, first, count)) return e;
-    it = g_pprograms.find(key);
+  if (plan.ident_off < 0) return "pixel kernel: the plan has no zero vector";
+  PixState* st = new (std::nothrow) PixState();
+  if (!st) return "pixel kernel: out of host memory";
+  st->zero4 = dp.prm + plan.ident_off + 32;
+  std::vector<float> arena;
+  for (int i = 0; i < (int)plan.ops.size(); ++i) {
+    const Op& op = plan.ops[i];
+    if (!op.chain || op.time_path || op.kind != OP_GEMM) continue;
+    if (const char* e = pix_gemm_supported(op.g)) { delete st; return e; }
+    pack_fragments(host_params, op.g, &st->fops[i], &arena);
   }
-  const PProgram& p = it->second;
-  const dim3 grid(plan.B), block(PNT);
-  const size_t ldsb = pix_lds_bytes(p.act_floats, p.ntaps);
-  if (g_prof_start) hipExtLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, g_prof_start, g_prof_stop, 0, p.d_ops, p.n_ops, plan.B, p.act_floats, p.d_taps, p.ntaps, g_pix_dbg);
-  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p.d_ops, p.n_ops, plan.B, p.act_floats, p.d_taps, p.ntaps, g_pix_dbg);
-  return nullptr;
-}
-
-int pixrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap) {
-  auto it = g_pprograms.find(std::make_pair((const void*)dp.plan, (long long)first * 4096 + count));
-  if (it == g_pprograms.end()) return -1;
-  std::vector<PixOpD> h(it->second.n_ops);
-  if (hipMemcpy(h.data(), it->second.d_ops, sizeof(PixOpD) * h.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  for (int i = 0; i < (int)h.size() && i < cap; ++i) kinds[i] = h[i].kind * 1000 + (h[i].kind == OP_GEMM ? h[i].tap_cnt : 0);
-  return (int)h.size();
-}
-
-// Build the programs of every maximal run of chain ops (model creation).  Any failure leaves those ops to the chain kernel.
-const char* pixrun_prepare(const DevPlan& dp) {
-  const Plan& plan = *dp.plan;
+  if (frag_mb) *frag_mb = arena.size() * 4.0 / 1e6;
+  if (arena.size() > 0xffffffffull) { delete st; return "pixel kernel: fragment arena too large"; }
+  static const double max_mb = std::getenv("SBM_PIX_MAX_MB") ? std::atof(std::getenv("SBM_PIX_MAX_MB")) : 48.0;
+  // every workgroup streams ALL of these bytes once per forward (about 110 GB/s per CU): beyond a few tens of MB the per-layer kernels,
+  // which share a weight tile among the samples of a tile, are faster (Unet(256): 300 MB)
+  if (arena.size() * 4.0 / 1e6 > max_mb) { delete st; return "pixel kernel: the low-resolution weights exceed SBM_PIX_MAX_MB (sample-owned streaming would be slower than the per-layer kernels)"; }
+  st->frag_floats = arena.size();
+  if (hipMalloc(&st->d_frag, arena.size() * sizeof(float) + 4096) != hipSuccess) { delete st; return "pixel kernel: hipMalloc failed"; }
+  if (hipMemcpy(st->d_frag, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(st->d_frag); delete st; return "pixel kernel: hipMemcpy failed"; }
+  ensure_dynamic_lds(reinterpret_cast<const void*>(pixrun_kernel), 160 * 1024);      // here, at model creation: per device and outside any stream capture
+  dp.pix = st;
   for (int i = 0; i < (int)plan.ops.size();) {
     if (!plan.ops[i].chain || plan.ops[i].time_path) { ++i; continue; }
     int n = 1;
     while (i + n < (int)plan.ops.size() && plan.ops[i + n].chain && !plan.ops[i + n].time_path) ++n;
-    if (const char* e = pixrun_build(dp, i, n)) return e;
+    PProgram p;
+    if (const char* e = pixrun_build(dp, *st, i, n, &p)) { pixrun_release(dp); return e; }
+    st->programs[(long long)i * 4096 + n] = p;
     i += n;
   }
   return nullptr;
 }
 
-void pixrun_release(const Plan* plan) {
-  for (auto it = g_pprograms.begin(); it != g_pprograms.end();) {
-    if (it->first.first == (const void*)plan) { (void)hipFree(it->second.d_ops); (void)hipFree(it->second.d_taps); it = g_pprograms.erase(it); }
-    else ++it;
+void pixrun_release(DevPlan& dp) {
+  PixState* st = dp.pix;
+  if (!st) return;
+  for (auto& kv : st->programs) free_program(kv.second);
+  (void)hipFree(st->d_frag);
+  delete st;
+  dp.pix = nullptr;
+}
+
+static const PProgram* pix_program(const DevPlan& dp, int first, int count, const char** err) {
+  PixState* st = dp.pix;
+  std::lock_guard<std::mutex> lock(st->mu);
+  const long long key = (long long)first * 4096 + count;
+  auto it = st->programs.find(key);
+  if (it == st->programs.end()) {                         // a sub-range (debug tools, op-by-op checks): built on demand, not capturable
+    PProgram p;
+    if (const char* e = pixrun_build(dp, *st, first, count, &p)) { *err = e; return nullptr; }
+    it = st->programs.emplace(key, p).first;
   }
+  return &it->second;
+}
+
+const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st) {
+  if (!dp.pix) return "pixel kernel: the model has no pixel state";
+  const Plan& plan = *dp.plan;
+  const char* err = nullptr;
+  const PProgram* p = pix_program(dp, first, count, &err);
+  if (!p) return err;
+  const dim3 grid(plan.B), block(PNT);
+  const size_t ldsb = pix_lds_bytes(p->act_floats, p->n_rowtab);
+  if (g_prof_start) hipExtLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, g_prof_start, g_prof_stop, 0, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab,
+                                          dp.pix->d_frag, plan.B, p->act_floats, g_pix_dbg);
+  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab, dp.pix->d_frag, plan.B, p->act_floats, g_pix_dbg);
+  return nullptr;
+}
+
+int pixrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap) {
+  if (!dp.pix) return -1;
+  const char* err = nullptr;
+  const PProgram* p = pix_program(dp, first, count, &err);
+  if (!p) return -1;
+  for (int i = 0; i < (int)p->kinds.size() && i < cap; ++i) kinds[i] = p->kinds[i];
+  return (int)p->kinds.size();
 }
 
 }  // namespace sbm

@@ -292,6 +292,7 @@ class Builder {
   void free_act(const View& v) { ws_free(v.off); }
   int64_t new_stats(int nparts, bool pin = false) { return ws_alloc((int64_t)nparts * B * 2, pin); }
   int chain_pix = 0;        // ops with P <= chain_pix are marked for the chain kernel
+  bool pix_mode = false;    // the marked ops are meant for the sample-owned pixel kernel (pixrun.hip) instead of the chain kernel
   int row_pix = 0;          // ... and of those, ops with P <= row_pix for the row kernel (rowrun.hip)
   // [tap][Npad][Kp] (k contiguous) -> [tap][Kp][Npad] (n contiguous): the row kernel streams weights with the output column on the lane
   int64_t add_transposed(const std::vector<float>& w, int ntap, int Npad, int Kp) {
@@ -405,10 +406,8 @@ class Builder {
                         ((P_out_px <= row_pix && P_in_px <= 4 * row_pix) || (P_in_px <= row_pix && P_out_px <= 4 * row_pix)) && P_in_px <= 4 && P_out_px <= 4;
     {
       std::vector<float> packed = pack_conv(s.w, s.cout, s.cin_true, s.kh, s.kw, s.cm, g.Kp, g.Npad, s.transposed, s.out_scale, s.gn ? s.gamma : nullptr);
-      // row-kernel ops and (pixrun.hip) the chain-level ops also keep a transposed copy [tap][Kp][Npad]
-      const bool pix_on = getenv("SBM_PIX") != nullptr;      // opt-in (read per plan, like SBM_CHAIN_PIX)
-      const bool pix_op = pix_on && chain_pix > 0 && P_out_px <= chain_pix && !s.out_nchw;
-      if (row_op || pix_op) g.wt_off = add_transposed(packed, s.kh * s.kw, g.Npad, g.Kp);
+      // row-kernel ops also keep a transposed copy [tap][Kp][Npad] (the pixel kernel packs its own fragment-order copies, pixrun.hip)
+      if (row_op) g.wt_off = add_transposed(packed, s.kh * s.kw, g.Npad, g.Kp);
       g.w_off = add_params(packed);
     }
     std::vector<double> bias(g.Npad, 0.0);
@@ -446,7 +445,7 @@ class Builder {
       g.has2 = 1; g.a2 = s.a2; g.up2 = s.up2;
       g.Kp2 = round_up(s.a2.C, 32);
       std::vector<float> packed2 = pack_conv(s.w2, s.cout, s.cin2, 1, 1, s.cm2, g.Kp2, g.Npad, false, nullptr);
-      if (row_op || (getenv("SBM_PIX") != nullptr && chain_pix > 0 && P_out_px <= chain_pix && !s.out_nchw)) g.wt2_off = add_transposed(packed2, 1, g.Npad, g.Kp2);
+      if (row_op) g.wt2_off = add_transposed(packed2, 1, g.Npad, g.Kp2);
       g.w2_off = add_params(packed2);
       if (s.bias2) { for (int n = 0; n < s.cout; ++n) bias[n] += s.bias2[n]; any_bias = true; }
     }
@@ -463,7 +462,9 @@ class Builder {
         min_taps = std::min(min_taps, nv);
       }
     choose_tile(B, P, nstore, &g.BM, &g.BN, s.kh * s.kw * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0), min_taps * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0));
-    if (chain_pix > 0 && P <= chain_pix && !s.out_nchw) { op.chain = 1; g.BM = 32; g.BN = 32; }
+    // pixel mode: the sample-owned kernel keeps 16 rows per LDS slab, so a convolution that READS a larger grid (the strided one from
+    // 8x8 down to 4x4) stays a per-layer launch
+    if (chain_pix > 0 && P <= chain_pix && !s.out_nchw && !(pix_mode && P_in_px > chain_pix)) { op.chain = 1; g.BM = 32; g.BN = 32; }
     if (row_op) { op.row = 1; op.chain = 0; g.BM = 32; g.BN = 32; }
     ConvResult res;
     if (s.out_nchw) {
@@ -651,6 +652,10 @@ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 }  // namespace
 
+static thread_local int g_plan_pix_mode = 0;
+void plan_set_pix_mode(int mode) { g_plan_pix_mode = mode; }
+int plan_pix_mode() { return g_plan_pix_mode; }
+
 int chain_pix_from_env(int B) {
   // The chain kernel gives each XCD (32 CUs) one 32-sample tile at a time: with fewer than ~6 tiles most of the chip idles
   // and per-layer launches are faster.
@@ -672,8 +677,14 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
   try {
     std::vector<TensorSpec> specs = unet_tensor_specs(cfg);
     Builder b(plan, B, specs, tensors);
-    b.chain_pix = chain_pix_from_env(B);
-    b.row_pix = b.chain_pix > 0 ? row_pix_from_env() : 0;
+    // Low-resolution levels (SBM_CHAIN_PIX pixels and fewer, default 16).  Pixel mode (default, api.hip tries it first): they are marked
+    // for the sample-owned kernel at EVERY batch size, the one-position level included, and the time path stays per-layer.  Legacy
+    // mode: XCD-resident chain kernel for B >= SBM_CHAIN_MIN_B plus the row kernel for the one-position level.
+    b.pix_mode = plan_pix_mode() == 1;
+    if (b.pix_mode) { const char* e = std::getenv("SBM_CHAIN_PIX"); const int v = e ? std::atoi(e) : 16; b.chain_pix = v < 0 ? 0 : (v > 16 ? 16 : v); b.row_pix = 0; }
+    else { b.chain_pix = chain_pix_from_env(B); b.row_pix = b.chain_pix > 0 ? row_pix_from_env() : 0; }
+    const int level_chain_pix = b.chain_pix;
+    if (b.pix_mode) b.chain_pix = 0;                                 // while the time path is emitted
     UnetDims d = unet_dims(cfg);
     const int n = (int)d.in_out.size();
     const int Hp = next_pow2(cfg.H), Wp = next_pow2(cfg.W);       // unet_model.py:276-284
@@ -735,6 +746,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       plan->cond_off = cond_off; plan->cond_ld = cond_ld;
       for (Op& o : plan->ops) if (o.kind != OP_NCHW_TO_PBC) { o.time_path = 1; if (o.row) { o.row = 0; o.chain = 1; } }      // everything emitted so far except the input conversion (the time MLP stays in the chain kernel)
     }
+    b.chain_pix = level_chain_pix;
     const size_t cond_op_index = plan->ops.size() - 1;
     std::vector<float> cond_w, cond_b;
     const int td_p = round_up(d.td, 32);

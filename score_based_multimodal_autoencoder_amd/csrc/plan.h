@@ -191,6 +191,10 @@ int chain_pix_from_env(int B);
 // Ops of the one-position (1x1) level -- and the strided convolutions that enter / leave it -- run in the row kernel when the chain
 // kernel is in use (SBM_ROW_PIX, default 1; 0 = keep them in the chain kernel).
 int row_pix_from_env();
+// How the next build_unet_plan of this thread marks the low-resolution ops: 0 legacy (chain kernel + row kernel, batch-size gated),
+// 1 pixel mode (sample-owned kernel, pixrun.hip: every batch size, the one-position level included, time path per-layer).
+void plan_set_pix_mode(int mode);
+int plan_pix_mode();
 
 struct UnetCfg {
   int dim = 64, channels = 3, init_dim = 0, out_dim = 0;

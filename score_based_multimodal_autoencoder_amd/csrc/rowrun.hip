@@ -552,8 +552,7 @@ static const char* rowrun_build(const DevPlan& dp, int first, int count) {
     for (RowOpD& d : b.ops) if (d.kind == OP_GEMM) d.ent = p.d_ents;
     if (hipMalloc(&p.d_ops, sizeof(RowOpD) * b.ops.size()) != hipSuccess) return "row kernel: hipMalloc failed";
     if (hipMemcpy(p.d_ops, b.ops.data(), sizeof(RowOpD) * b.ops.size(), hipMemcpyHostToDevice) != hipSuccess) return "row kernel: hipMemcpy failed";
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowrun_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    ensure_dynamic_lds(reinterpret_cast<const void*>(rowrun_kernel), 160 * 1024);
     g_programs.emplace(key, p);
   }
   return nullptr;

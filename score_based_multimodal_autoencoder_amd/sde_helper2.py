@@ -184,6 +184,8 @@ def apply_guidance_(x, t, score, cl_g, cl_s, given, all_mods, poly_pairs=False):
     if poly_pairs:
         mod1 = given[torch.randint(len(given), (1,)).item()]
         mod2 = predicted[torch.randint(len(predicted), (1,)).item()]
+        if cl_s is None:                                           # train_poly_unet_cont.py:86-88, 143-145: no scale, no update -- but the two
+            return score                                           # randint draws above have been made, so the RNG stream matches
         jobs.append((cl_g, int(mod1) - base, int(mod2) - base, (False, True), True))
     else:
         for m1, m2 in (("0", "1"), ("0", "2"), ("1", "2")):

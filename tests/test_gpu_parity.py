@@ -363,13 +363,15 @@ def test_time_table_is_bit_identical_to_per_step_time_path(pkg):
 
 
 def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
-    """Config-2 score net, B=256 (8 sample tiles = 8 XCD clusters): XCD-resident chain vs one launch per layer."""
+    """Config-2 score net, B=256 (8 sample tiles = 8 XCD clusters): XCD-resident chain (the LEGACY path, SBM_PIX=0) vs one launch per
+    layer."""
     import ctypes
     m = _unet(pkg, "P5")
     x = torch.randn(256, 5, 8, 8, device="cuda")
     t = torch.rand(256, device="cuda")
     import os
     outs = {}
+    os.environ["SBM_PIX"] = "0"
     for pix in ("0", "16"):
         os.environ["SBM_CHAIN_PIX"] = pix
         try:
@@ -384,14 +386,17 @@ def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
         finally:
             os.environ.pop("SBM_CHAIN_PIX", None)
             m.release_engines()
+    os.environ.pop("SBM_PIX", None)
     scale = float(outs["0"].abs().max())
     assert float((outs["0"] - outs["16"]).abs().max()) <= 2e-5 * scale
     assert torch.isfinite(outs["16"]).all()
 
 
 def test_pixel_kernel_matches_per_layer_kernels_at_bench_size(pkg):
-    """SBM_PIX=1 (opt-in): the 4x4 / 2x2 levels as sample-owned workgroups (csrc/pixrun.hip: one sample per workgroup, activations in
-    LDS, pixels on the MFMA rows) against one launch per layer, config-2 score net at B = 256; and a 20-step sampler run through it."""
+    """The DEFAULT path: the 4x4 / 2x2 / 1x1 levels as ONE launch of sample-owned workgroups (csrc/pixrun.hip: one sample per workgroup,
+    activations in LDS, weights streamed in MFMA fragment order) against one launch per layer (SBM_CHAIN_PIX=0), config-2 score net at
+    B = 256; a 20-step sampler run through both; and -- sample ownership -- a sample's low-resolution result does not depend on the batch
+    it is in: the B = 64 engine reproduces the rows of the B = 256 one to the 8x8 levels' reassociation."""
     import ctypes
     import os
     from score_based_multimodal_autoencoder_amd.sde_helper2 import VPSDE, uncond_sampler
@@ -400,19 +405,23 @@ def test_pixel_kernel_matches_per_layer_kernels_at_bench_size(pkg):
     t = torch.rand(256, device="cuda")
     sde = VPSDE(0.1, 5.0, 20)
     outs, runs = {}, {}
-    for tag, env in (("layers", {"SBM_CHAIN_PIX": "0"}), ("pix", {"SBM_CHAIN_PIX": "16", "SBM_PIX": "1"})):
+    for tag, env in (("layers", {"SBM_CHAIN_PIX": "0"}), ("pix", {})):
         os.environ.update(env)
         try:
             m.release_engines()
             for _ in range(2):
                 y = m(x, t)
             outs[tag] = y.clone()
+            eng = m._engine_for(256, 8, 8)
             if tag == "pix":
-                eng = m._engine_for(256, 8, 8)
-                st = (ctypes.c_uint64 * 256)(); kinds = (ctypes.c_int * 256)(); nout = ctypes.c_int(0)
+                assert eng.info["uses_pix"] and 5.0 < eng.info["pix_fragment_mb"] < 48.0, eng.info
+                st = (ctypes.c_uint64 * 512)(); kinds = (ctypes.c_int * 512)(); nout = ctypes.c_int(0)
                 L = pkg["lib"].lib()
-                active = [i for i in range(eng.info["n_ops"]) if L.sbm_debug_pix_stamps(eng.h, i, 1, st, kinds, 256, ctypes.byref(nout)) == 0]
-                assert len(active) >= 40, "the pixel kernel must be the one that ran the low-resolution ops"
+                active = [i for i in range(eng.info["n_ops"]) if L.sbm_debug_pix_stamps(eng.h, i, 1, st, kinds, 512, ctypes.byref(nout)) == 0]
+                assert len(active) >= 60, "the pixel kernel must be the one that ran the low-resolution ops (the one-position level included)"
+                small = m(x[:64], t[:64]).clone()
+                assert m._engine_for(64, 8, 8).info["uses_pix"]
+                assert float((small - outs["pix"][:64]).abs().max()) <= 2e-5 * float(outs["pix"].abs().max())
             runs[tag] = uncond_sampler((256, 5, 8, 8), m, "cuda", sde, x0=x, seed=5).clone()
         finally:
             for k in env:
@@ -425,7 +434,7 @@ def test_pixel_kernel_matches_per_layer_kernels_at_bench_size(pkg):
 
 def test_full_size_sampling_run_is_path_and_shard_independent(pkg):
     """BASELINE config 2 at full size (B = 256, 1000 reverse-SDE steps, in-kernel Philox noise): the samples do not depend on
-    WHICH kernels carry the low-resolution levels (XCD-resident chain vs one launch per layer) beyond float32 reassociation, nor
+    WHICH kernels carry the low-resolution levels (the sample-owned pixel kernel vs one launch per layer) beyond float32 reassociation, nor
     on how the batch is split (two shards of 128 keyed by their global sample offset = the unsharded run, bit for bit per path)."""
     import os
     from score_based_multimodal_autoencoder_amd.sde_helper2 import VPSDE, uncond_sampler
@@ -443,8 +452,8 @@ def test_full_size_sampling_run_is_path_and_shard_independent(pkg):
                 again = uncond_sampler((256, 5, 8, 8), m, "cuda", sde, x0=x0, seed=7, sample_offset=0)
                 assert torch.equal(again, outs[pix]), "the run must be deterministic"
                 halves = [uncond_sampler((128, 5, 8, 8), m, "cuda", sde, x0=x0[o:o + 128], seed=7, sample_offset=o) for o in (0, 128)]
-                # a 128-sample engine takes the per-layer kernels for some levels (fewer tiles than XCDs are allowed, but the
-                # tile GEMMs differ): same trajectory up to reassociation
+                # the low-resolution levels are sample-owned (identical per sample in any batch); the 8x8 levels of a 128-sample engine
+                # use a different tile / split-K plan: same trajectory up to reassociation
                 d = float((torch.cat(halves) - outs[pix]).abs().max())
                 assert d <= 5e-3 * float(outs[pix].abs().max()), d
         finally:

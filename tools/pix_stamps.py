@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Per-op time inside the pixel kernel (stamps of workgroup 0), config-2 score net at B=256: both runs (down / up)."""
+"""Per-op time inside the pixel kernel (stamps of workgroup 0), config-2 score net at B=256: every run of low-resolution ops.
+With PIX_PHASES=1 every GEMM pass also shows its phases: K loop | partial tiles + barrier | epilogue + barrier."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,6 +9,9 @@ from score_based_multimodal_autoencoder_amd.unet_model import Unet
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 m = synth.fill_module_(Unet(dim=64, channels=5, dim_mults=(1, 2, 2, 2)).eval()).cuda()
 eng = m._engine_for(B, 8, 8)
+print("uses_pix", eng.info["uses_pix"], "fragment MB %.1f" % eng.info["pix_fragment_mb"], "note:", eng.info["pix_note"])
+if not eng.info["uses_pix"]:
+    sys.exit(1)
 x = torch.randn(B, 5, 8, 8, device="cuda"); t = torch.rand(B, device="cuda"); o = torch.empty_like(x)
 for _ in range(3): eng.forward(x, t, o)
 torch.cuda.synchronize()
@@ -15,8 +19,9 @@ L = _lib.lib(); n = eng.info["n_ops"]; buf = ctypes.create_string_buffer(256)
 names = []
 for i in range(n):
     L.sbm_debug_op_name(eng.h, i, buf, 256); names.append(buf.value.decode())
-st = (ctypes.c_uint64 * 256)(); kinds = (ctypes.c_int * 256)(); nout = ctypes.c_int(0)
-ok = [L.sbm_debug_pix_stamps(eng.h, i, 1, st, kinds, 256, ctypes.byref(nout)) == 0 for i in range(n)]
+CAP = 512
+st = (ctypes.c_uint64 * CAP)(); kinds = (ctypes.c_int * CAP)(); nout = ctypes.c_int(0)
+ok = [L.sbm_debug_pix_stamps(eng.h, i, 1, st, kinds, CAP, ctypes.byref(nout)) == 0 for i in range(n)]
 runs, i = [], 0
 while i < n:
     if ok[i]:
@@ -26,19 +31,24 @@ while i < n:
     else:
         i += 1
 KN = {0: "gemm", 1: "dw", 2: "linattn", 4: "gn_res", 101: "(stage)"}
+CLK = float(os.environ.get("PIX_CLOCK_MHZ", "2100"))          # s_memtime counts shader cycles; the clock under this load is ~2.1 GHz
 for first, last in runs:
-    _lib.check(L.sbm_debug_pix_stamps(eng.h, first, last - first + 1, st, kinds, 256, ctypes.byref(nout)))
+    _lib.check(L.sbm_debug_pix_stamps(eng.h, first, last - first + 1, st, kinds, CAP, ctypes.byref(nout)))
     full = list(st); v = full[:nout.value + 1]; k = list(kinds)[:nout.value]
-    j = first
+    j = first; item = 0; tot = {}
     print(f"run: ops {first}..{last}")
     for i in range(nout.value):
-        kind, taps = k[i] // 1000, k[i] % 1000
+        kind, passes = k[i] // 1000, k[i] % 1000
         nm = "(stage)" if kind == 101 else names[j]
         if kind != 101: j += 1
         extra = ""
-        if kind == 0 and i < 30 and os.environ.get("PIX_PHASES"):
-            ph = [full[64 + i * 6 + j] for j in range(5)]
-            if all(ph):
-                extra = "   | taps+sync %.2f  fill %.2f  kloop %.2f  partials+sync %.2f  epilogue+sync %.2f (last pass)" % tuple((b_ - a_) / 2400.0 for a_, b_ in zip([v[i]] + ph[:4], ph))
-        print(f"  {nm[:52]:52s} {KN.get(kind, kind):8} {(v[i + 1] - v[i]) / 2400.0:8.2f} us" + (f"   {taps} taps" if taps else "") + extra)
-    print(f"  total {(v[-1] - v[0]) / 2400.0:.1f} us for {nout.value} program ops")
+        if kind == 0:
+            if os.environ.get("PIX_PHASES"):
+                for p in range(passes):
+                    ph = [full[128 + (item + p) * 4 + q] for q in range(4)] if item + p < 60 else [0] * 4
+                    if all(ph): extra += "   | kloop %.2f  partials+sync %.2f  epilogue+sync %.2f" % tuple((b_ - a_) / CLK for a_, b_ in zip(ph[:3], ph[1:]))
+            item += passes
+        us = (v[i + 1] - v[i]) / CLK
+        tot[KN.get(kind, kind)] = tot.get(KN.get(kind, kind), 0.0) + us
+        print(f"  {nm[:52]:52s} {KN.get(kind, kind):8} {us:8.2f} us" + (f"   {passes} passes" if kind == 0 else "") + extra)
+    print(f"  total {(v[-1] - v[0]) / CLK:.1f} us for {nout.value} program ops; by kind: " + ", ".join(f"{a} {b:.1f}" for a, b in tot.items()))

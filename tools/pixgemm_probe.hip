@@ -273,6 +273,109 @@ __global__ __launch_bounds__(NW * 64) void gemm_chain(const PItem* __restrict__ 
   for (int i = tid; i < 16 * Cl; i += NW * 64) { const int r = i / Cl, k = i - r * Cl; out[(long long)b * 16 * Cl + i] = lds[outl_off + (k >> 4) * CS + r * 16 + (k & 15)]; }
 }
 
+// ---- the same chain for at most FOUR output rows (the 2x2 and 1x1 levels): v_mfma_f32_4x4x1_16b_f32, 16 blocks = 16 column quads
+// (64 columns per wave) sharing one k; a step = 16 k x 64 columns = 4 KB: load j holds W[n = 64 tile + lane][k = 16 dc + 4 j + i].
+// Lane (b, i) = (lane >> 2, lane & 3) supplies A[row i][k]; lane l receives D[row v][column l] in register v (checked numerically here).
+#define MF4(ACC, A, B) "v_mfma_f32_4x4x1_16b_f32 " ACC ", " A ", a" #B ", " ACC "\n\t"
+#define RING_MFMA4(acc0, acc1, q0, q1, q2, q3, WAITN, B0, B1, B2, B3, B4, B5, B6, B7, B8, B9, B10, B11, B12, B13, B14, B15) \
+  asm volatile("s_waitcnt vmcnt(" #WAITN ")\n\t" \
+               MF4("%0", "%2", B0) MF4("%1", "%3", B1) MF4("%0", "%4", B2) MF4("%1", "%5", B3) MF4("%0", "%6", B4) MF4("%1", "%7", B5) MF4("%0", "%8", B6) MF4("%1", "%9", B7) \
+               MF4("%0", "%10", B8) MF4("%1", "%11", B9) MF4("%0", "%12", B10) MF4("%1", "%13", B11) MF4("%0", "%14", B12) MF4("%1", "%15", B13) MF4("%0", "%16", B14) "v_mfma_f32_4x4x1_16b_f32 %1, %17, a" #B15 ", %1" \
+               : "+v"(acc0), "+v"(acc1) : "v"(q0[0]), "v"(q0[1]), "v"(q0[2]), "v"(q0[3]), "v"(q1[0]), "v"(q1[1]), "v"(q1[2]), "v"(q1[3]), \
+                 "v"(q2[0]), "v"(q2[1]), "v"(q2[2]), "v"(q2[3]), "v"(q3[0]), "v"(q3[1]), "v"(q3[2]), "v"(q3[3]))
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_chain_small(const PItem* __restrict__ items, int nitems, const PStep* __restrict__ steps, const unsigned char* __restrict__ rowtab, int nrowtab,
+                                                            const float* __restrict__ arena, const float* __restrict__ x0, int C0, int in0_off, float* __restrict__ out, int Cl, int outl_off,
+                                                            int act_floats, unsigned long long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* red = lds + act_floats;           // [NW][4 rows][64 cols]
+  unsigned char* rtab = reinterpret_cast<unsigned char*>(red + NW * 512);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ri = lane & 3;
+  const int b = blockIdx.x;
+  for (int i = tid; i < act_floats; i += NW * 64) lds[i] = 0.f;
+  for (int i = tid; i < nrowtab * 16; i += NW * 64) rtab[i] = rowtab[i];
+  __syncthreads();
+  {
+    const float sc = 1.0f + (float)(b & 7) * 0.125f;
+    for (int i = tid; i < 16 * C0; i += NW * 64) { const int r = i / C0, k = i - r * C0; lds[in0_off + (k >> 4) * CS + r * 16 + (k & 15)] = x0[i] * sc; }
+  }
+  __syncthreads();
+  unsigned asel[D];
+  auto lane_off = [&](const PItem& it) { return (unsigned)(((wave & ((1 << it.tshift) - 1)) * it.pair_stride + lane * 4) * 4); };
+  auto slice_steps = [&](const PItem& it) { return steps + it.step_base + (wave >> it.tshift) * it.nkp; };
+#define MFMA4_SLOT(r) do { \
+    if (r == 0) RING_MFMA4(acc0, acc1, q0, q1, q2, q3, 12, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15); \
+    else if (r == 1) RING_MFMA4(acc0, acc1, q0, q1, q2, q3, 12, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31); \
+    else if (r == 2) RING_MFMA4(acc0, acc1, q0, q1, q2, q3, 12, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47); \
+    else RING_MFMA4(acc0, acc1, q0, q1, q2, q3, 12, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63); } while (0)
+  PItem cur = items[0];
+  unsigned off_c = lane_off(cur);
+  const PStep* st_c = slice_steps(cur);
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    const PStep e = st_c[r];
+    asel[r] = e.a_sel;
+    LOAD_SLOT(r, e, off_c);
+  }
+  int rs = rtab[(asel[0] >> 16) * 16 + ri];
+  const float* ap0 = lds + (asel[0] & 0xffff) + rs * 16;
+  f32x4 q0 = *reinterpret_cast<const f32x4*>(ap0), q1 = *reinterpret_cast<const f32x4*>(ap0 + 4), q2 = *reinterpret_cast<const f32x4*>(ap0 + 8), q3 = *reinterpret_cast<const f32x4*>(ap0 + 12);
+  rs = rtab[(asel[1] >> 16) * 16 + ri];
+  for (int ii = 0; ii < nitems; ++ii) {
+    const PItem nxt = items[ii + 1 < nitems ? ii + 1 : 0];
+    const unsigned off_n = lane_off(nxt);
+    const PStep* st_n = slice_steps(nxt);
+    if (stamps && b == 0 && tid == 0) stamps[ii * 4 + 0] = __builtin_amdgcn_s_memtime();
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    const int nu = cur.nkp / D;
+    for (int u = 0; u < nu; ++u) {
+      const bool last = u == nu - 1;
+      const PStep* lst = last ? st_n : st_c + (u + 1) * D;
+      const unsigned loff = last ? off_n : off_c;
+#pragma unroll
+      for (int r = 0; r < D; ++r) {
+        const float* apn = lds + (asel[(r + 1) % D] & 0xffff) + rs * 16;
+        const f32x4 n0 = *reinterpret_cast<const f32x4*>(apn), n1 = *reinterpret_cast<const f32x4*>(apn + 4), n2 = *reinterpret_cast<const f32x4*>(apn + 8), n3 = *reinterpret_cast<const f32x4*>(apn + 12);
+        const PStep e = lst[r];
+        MFMA4_SLOT(r);
+        asel[r] = e.a_sel;
+        rs = rtab[(asel[(r + 2) % D] >> 16) * 16 + ri];
+        LOAD_SLOT(r, e, loff);
+        q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+      }
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc0), "+v"(acc1));
+    if (stamps && b == 0 && tid == 0) stamps[ii * 4 + 1] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+    for (int v = 0; v < 4; ++v) red[(wave * 4 + v) * 64 + lane] = acc0[v] + acc1[v];
+    __syncthreads();
+    if (stamps && b == 0 && tid == 0) stamps[ii * 4 + 2] = __builtin_amdgcn_s_memtime();
+    const int tiles = 1 << cur.tshift, ksplit = 1 << cur.kshift, quads = tiles * 16;
+    for (int idx = tid; idx < 4 * quads; idx += NW * 64) {
+      const int row = idx / quads, c4 = idx - row * quads, tl = c4 >> 4, sub = c4 & 15;
+      f32x4 s = {0, 0, 0, 0};
+      for (int sl = 0; sl < ksplit; ++sl) s += *reinterpret_cast<const f32x4*>(red + ((sl * tiles + tl) * 4 + row) * 64 + 4 * sub);
+      const int col = (cur.tile0 + tl) * 64 + 4 * sub;
+      const f32x4 bi = *reinterpret_cast<const f32x4*>(cur.bias + col);
+      f32x4 y;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) y[e] = gelu(s[e] + bi[e]) * cur.oscale;
+      *reinterpret_cast<f32x4*>(lds + cur.out_off + (col >> 4) * CS + row * 16 + (col & 15)) = y;
+    }
+    __syncthreads();
+    if (stamps && b == 0 && tid == 0) stamps[ii * 4 + 3] = __builtin_amdgcn_s_memtime();
+    {
+      int rs0 = rtab[(asel[0] >> 16) * 16 + ri];
+      const float* apn = lds + (asel[0] & 0xffff) + rs0 * 16;
+      q0 = *reinterpret_cast<const f32x4*>(apn); q1 = *reinterpret_cast<const f32x4*>(apn + 4); q2 = *reinterpret_cast<const f32x4*>(apn + 8); q3 = *reinterpret_cast<const f32x4*>(apn + 12);
+    }
+    cur = nxt; off_c = off_n; st_c = st_n;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: RING_CLOBBER_0, RING_CLOBBER_1, RING_CLOBBER_2, RING_CLOBBER_3);
+  for (int i = tid; i < 16 * Cl; i += NW * 64) { const int r = i / Cl, k = i - r * Cl; out[(long long)b * 16 * Cl + i] = lds[outl_off + (k >> 4) * CS + r * 16 + (k & 15)]; }
+}
+
 static float frand(unsigned& s) { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; }
 
 struct HostOp { int N, Kp, ntap, in_off, out_off; long long w_off, b_off, wf_off; float oscale; signed char src[16][16]; };
@@ -289,6 +392,47 @@ static void pack_fragments(const std::vector<float>& arena_in, const HostOp& o, 
       blk[((h * 2 + t) * 64 + lane) * 4 + i] = arena_in[o.w_off + ((size_t)tap * o.N + nn) * o.Kp + k];
     }
   }
+}
+// small path: [tile of 64 columns][step f = tap * (Kp / 16) + dc][k group j][lane][4]
+static void pack_fragments_small(const std::vector<float>& arena_in, const HostOp& o, std::vector<float>* out) {
+  const int ndc = o.Kp / 16, F = o.ntap * ndc, tiles = o.N / 64;
+  out->assign((size_t)tiles * F * 1024, 0.f);
+  for (int tl = 0; tl < tiles; ++tl) for (int f = 0; f < F; ++f) {
+    const int tap = f / ndc, dc = f % ndc;
+    float* blk = out->data() + ((size_t)tl * F + f) * 1024;
+    for (int j = 0; j < 4; ++j) for (int lane = 0; lane < 64; ++lane) for (int i = 0; i < 4; ++i)
+      blk[(j * 64 + lane) * 4 + i] = arena_in[o.w_off + ((size_t)tap * o.N + 64 * tl + lane) * o.Kp + 16 * dc + 4 * j + i];
+  }
+}
+static Tables build_tables_small(const std::vector<HostOp>& ops, int NW, int D, const float* d_arena) {
+  Tables t;
+  t.rowtab.assign(16, 16);
+  for (const HostOp& o : ops) {
+    const int first_tab = (int)t.rowtab.size() / 16;
+    for (int tp = 0; tp < o.ntap; ++tp) for (int r = 0; r < 16; ++r) t.rowtab.push_back(o.src[tp][r] < 0 ? 16 : (unsigned char)o.src[tp][r]);
+    const int T = o.N / 64, ndc = o.Kp / 16, F = o.ntap * ndc;
+    for (int t0 = 0; t0 < T;) {
+      int tiles = 1; while (tiles * 2 <= NW && tiles * 2 <= T - t0) tiles *= 2;
+      const int ksplit = NW / tiles;
+      const int nk = (F + ksplit - 1) / ksplit, nkp = (nk + D - 1) / D * D;
+      PItem it{};
+      it.step_base = (int)t.steps.size(); it.nkp = nkp; it.tile0 = t0; it.pair_stride = F * 1024; it.out_off = o.out_off; it.oscale = o.oscale;
+      it.bias = d_arena + o.b_off;
+      int sh = 0; while ((1 << sh) < tiles) ++sh; it.tshift = sh;
+      sh = 0; while ((1 << sh) < ksplit) ++sh; it.kshift = sh;
+      for (int sl = 0; sl < ksplit; ++sl)
+        for (int j = 0; j < nkp; ++j) {
+          const int f = sl + j * ksplit;
+          PStep e;
+          if (f < F) { const int tp = f / ndc, dc = f % ndc; e.w_off = (unsigned)(o.wf_off + ((long long)t0 * F + f) * 1024); e.a_sel = (unsigned)(o.in_off + dc * CS) | ((unsigned)(first_tab + tp) << 16); }
+          else { e.w_off = (unsigned)(o.wf_off + (long long)t0 * F * 1024); e.a_sel = (unsigned)o.in_off; }
+          t.steps.push_back(e);
+        }
+      t.items.push_back(it);
+      t0 += tiles;
+    }
+  }
+  return t;
 }
 // rowtab entry 0 is the no-op table (all rows -> the zero row 16)
 static Tables build_tables(const std::vector<HostOp>& ops, int NW, int D, const float* d_arena) {
@@ -379,10 +523,15 @@ int main(int argc, char** argv) {
       for (int i = 0; i < cout; ++i) arena.push_back(frand(seed) * 0.1f);
       total_mb += 9.0 * cout * cin * 4 / 1e6; flop += 2.0 * 16 * 9 * cin * cout;
     }
+    std::vector<long long> wf_big(nops), wf_small(nops);
     for (int k = 0; k < nops; ++k) {                             // fragment-order copies behind the reference layout
       std::vector<float> fr; pack_fragments(arena, ops[k], &fr);
-      ops[k].wf_off = (long long)arena.size();
+      wf_big[k] = (long long)arena.size();
       arena.insert(arena.end(), fr.begin(), fr.end());
+      pack_fragments_small(arena, ops[k], &fr);
+      wf_small[k] = (long long)arena.size();
+      arena.insert(arena.end(), fr.begin(), fr.end());
+      ops[k].wf_off = wf_big[k];
     }
     const int C0 = 128, Cl = 128;
     std::vector<float> x0(16 * C0); for (auto& v : x0) v = frand(seed);
@@ -409,8 +558,9 @@ int main(int argc, char** argv) {
     float* d_out; CK(hipMalloc(&d_out, (size_t)256 * 16 * Cl * 4));
     unsigned long long* d_st; CK(hipMalloc(&d_st, 64 * 4 * 8));
     printf("GEMM chain (%s): %d convolutions 3x3, %.2f MB of weights and %.1f MFLOP (16-row) per workgroup, 256 workgroups\n", small ? "2x2" : "4x4", nops, total_mb, flop / 1e6);
-    auto run = [&](auto kern, int NW, int D, const char* tag) {
-      Tables t = build_tables(ops, NW, D, d_arena);
+    auto run = [&](auto kern, int NW, int D, const char* tag, bool small_path = false) {
+      for (int k = 0; k < nops; ++k) ops[k].wf_off = small_path ? wf_small[k] : wf_big[k];
+      Tables t = small_path ? build_tables_small(ops, NW, D, d_arena) : build_tables(ops, NW, D, d_arena);
       PItem* d_items; PStep* d_steps; unsigned char* d_rt;
       CK(hipMalloc(&d_items, t.items.size() * sizeof(PItem))); CK(hipMemcpy(d_items, t.items.data(), t.items.size() * sizeof(PItem), hipMemcpyHostToDevice));
       CK(hipMalloc(&d_steps, t.steps.size() * sizeof(PStep))); CK(hipMemcpy(d_steps, t.steps.data(), t.steps.size() * sizeof(PStep), hipMemcpyHostToDevice));
@@ -431,7 +581,7 @@ int main(int argc, char** argv) {
       std::vector<float> got((size_t)256 * 16 * Cl);
       CK(hipMemcpy(got.data(), d_out, got.size() * 4, hipMemcpyDeviceToHost));
       double maxerr = 0, maxref = 0;
-      for (int bb : {0, 3, 255}) for (int i = 0; i < 16 * Cl; ++i) {
+      for (int bb : {0, 3, 255}) for (int i = 0; i < (small_path ? 4 : 16) * Cl; ++i) {      // the 4-row path never writes the idle rows
         const double r = ref[(size_t)(bb & 7) * 16 * Cl + i];
         maxerr = std::max(maxerr, std::fabs((double)got[(size_t)bb * 16 * Cl + i] - r)); maxref = std::max(maxref, std::fabs(r));
       }
@@ -445,8 +595,11 @@ int main(int argc, char** argv) {
       CK(hipFree(d_items)); CK(hipFree(d_steps)); CK(hipFree(d_rt));
     };
     run(gemm_chain<8>, 8, 4, "8 waves, depth 4");
-    run(gemm_chain<16>, 16, 4, "16 waves, depth 4");
-    run(gemm_chain<4>, 4, 4, "4 waves, depth 4");
+    if (small) {
+      run(gemm_chain_small<8>, 8, 4, "8 waves, 4x4x1 path", true);
+      run(gemm_chain_small<16>, 16, 4, "16 waves, 4x4x1 path", true);
+      run(gemm_chain_small<4>, 4, 4, "4 waves, 4x4x1 path", true);
+    }
     CK(hipFree(d_arena)); CK(hipFree(d_x0)); CK(hipFree(d_out)); CK(hipFree(d_st));
     }
   }
