@@ -51,24 +51,30 @@ constexpr int P_RED_F = PNW * 512, P_STAT_SLOTS = 64, P_SCR_F = 4352;
 
 struct PixStep { unsigned w_off; unsigned a_sel; };   // w_off: float offset (fragment arena) of the step's block for column group 0 of the pass;
                                                       // a_sel = LDS float offset of the step's first chunk | row table << 16 | source 2 << 31
-struct PixItem {                          // one pass of a GEMM: up to 8 column groups (32 columns, or 64 on the 4-row path)
+enum : int { PIF_SMALL = 1, PIF_GN = 2, PIF_SCALE2 = 4, PIF_FIRST = 8, PIF_LAST = 16 };
+struct PixItem {                          // one pass of a GEMM: up to 8 column groups (32 columns, or 64 on the 4-row path) -- and EVERYTHING the pass needs,
+                                          // so that the kernel reads nothing but this table (scalar loads) on the GEMM path
   int step_base, nkp;                     // step lists of the K slices: step_base + slice * nkp, nkp a multiple of PD
   int gshift, kshift;                     // log2(column groups of the pass), log2(K slices) -- groups * slices = 8 waves
   int grp0, grp_stride;                   // first column group; floats between the blocks of consecutive groups
-  int small, pad;                         // 1: the 4-row path
+  int flags, P_out;                       // PIF_*: 4-row path, folded GroupNorm on source 1, source 2 enters unnormalised, first / last pass of its op
+  int Npad, nstore, act, ldo;
+  int gn_stat, stat_out, out_lds, res_lds; // LDS statistics slots consumed / produced (-1 none), output / residual slabs (-1 none)
+  float gn_inv; int rowstride;            // 1 / (channels x pixels) of the GroupNorm; Npad when the folded-GroupNorm tables are per output pixel, else 0
+  int res_row[4];                         // 16 bytes: residual row of output row r
+  int pad0, pad1;
+  const float* bias; const float* gn_s; const float* gn_b1;     // never null: a zero vector stands in
+  float* out_g; float2* stat_g;           // workspace copies of the output / its statistics, when something outside the launch reads them
+  long long pad2;
 };
+static_assert(sizeof(PixItem) == 144, "PixItem layout");
 
 struct PixOpD {
   int kind;                              // OP_GEMM, OP_DWCONV7, OP_GN_RES, OP_LINATTN, PIX_STAGE
-  int item0, nitems;                     // GEMM: its passes
-  int P_out, Npad, nstore, act, ldo, nblk, scale2;
+  int nitems;                            // GEMM: its passes (consecutive entries of the item table)
   int gn_stat, stat_out;                 // LDS statistics slots consumed / produced, -1 none
-  int in_lds, out_lds, res_lds, x_lds;
-  int res_row[4];                        // 16 bytes: residual row of output row r
-  float gn_inv;
-  const float* bias; const float* gn_s; const float* gn_b1;     // never null: a zero vector stands in
-  int gn_rowstride;                      // Npad (folded GroupNorm tables are per output pixel) or 0
-  float* out_g; float2* stat_g;
+  int in_lds, out_lds, x_lds, pad;
+  float* out_g; float2* stat_g;          // non-null: the result / its statistics also go to the workspace
   DwArgs dw; GnResArgs gr; AttnArgs at;
   const float* st_src; const float2* st_part; int st_ld, st_C, st_P, st_lds, st_stat, st_nparts;
 };
@@ -90,15 +96,9 @@ __device__ __forceinline__ float pix_act(int act, float v) {
 // cannot prove the tables unclobbered -- and every vector load drags a compiler-placed s_waitcnt vmcnt(0) into the K loop, which drains
 // the weight ring.
 typedef int i32x2p __attribute__((ext_vector_type(2)));
-typedef int i32x8p __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ PixStep ldc_step(const PixStep* p) {
   const i32x2p v = *(const __attribute__((address_space(4))) i32x2p*)(unsigned long long)p;
   return PixStep{(unsigned)v[0], (unsigned)v[1]};
-}
-__device__ __forceinline__ PixItem ldc_item(const PixItem* p) {
-  const i32x8p v = *(const __attribute__((address_space(4))) i32x8p*)(unsigned long long)p;
-  PixItem it; it.step_base = v[0]; it.nkp = v[1]; it.gshift = v[2]; it.kshift = v[3]; it.grp0 = v[4]; it.grp_stride = v[5]; it.small = v[6]; it.pad = v[7];
-  return it;
 }
 template <typename T> __device__ __forceinline__ T ldc(const T* p) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8, "ldc: 4- or 8-byte fields");
@@ -164,159 +164,206 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
 }  // namespace
 
 __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict__ ops, int count, const PixItem* __restrict__ items, int nitems, const PixStep* __restrict__ steps,
-                                                        const unsigned char* __restrict__ rowtab, int nrowtab, const float* __restrict__ frag, int B, int act_floats,
-                                                        unsigned long long* dbg) {
+                                                        const unsigned char* __restrict__ rowtab, int nrowtab, const float* __restrict__ frag, const StepCtl* __restrict__ ctl, int B,
+                                                        int act_floats, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* red = lds + act_floats;                         // [8 waves][512]: 16 rows x 32 columns, or 4 rows x 64 columns
-  float* stat = red + P_RED_F;                           // [slots][2]
-  float* scr = stat + P_STAT_SLOTS * 2;                  // scratch (LinearAttention contexts, reductions)
+  float* stat = red + P_RED_F;                           // [slots][8 waves][2]: per-wave partial (sum, sumsq); readers add the eight in wave order
+  float* scr = stat + P_STAT_SLOTS * PNW * 2;            // scratch (LinearAttention contexts)
   unsigned char* rtab = reinterpret_cast<unsigned char*>(scr + P_SCR_F);   // [nrowtab][16]: source row of output row r (16 = the zero row)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   for (int i = tid; i < act_floats + P_RED_F; i += PNT) lds[i] = 0.f;
   for (int i = tid; i < nrowtab * 16; i += PNT) rtab[i] = rowtab[i];
+  // the time conditions of the depth-wise ops: the step's row of the sampler's table, resolved once per launch
+  const float* cond_tab = nullptr;
+  if (ctl && ctl->table_mode) cond_tab = ctl->table + (long long)ctl->step * ctl->tab_ld;
   __syncthreads();
+  auto stat_sum = [&](int slot, float* su, float* sq) {
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int w = 0; w < PNW; ++w) { a += stat[(slot * PNW + w) * 2]; q += stat[(slot * PNW + w) * 2 + 1]; }
+    *su = a; *sq = q;
+  };
   // ---- loader state (per wave; survives the non-GEMM ops between two GEMMs) ----
   unsigned asel[PD];
-  auto lane_off = [&](const PixItem& it) { return (unsigned)(((wave & ((1 << it.gshift) - 1)) * it.grp_stride + lane * 4) * 4); };   // bytes
-  auto slice_steps = [&](const PixItem& it) { return steps + it.step_base + (wave >> it.gshift) * it.nkp; };
-  int ci = 0;
-  PixItem cur = ldc_item(items);
-  unsigned off_c = lane_off(cur);
-  const PixStep* st_c = slice_steps(cur);
-  {
+  auto lane_off = [&](const PixItem* it) { return (unsigned)(((wave & ((1 << ldc(&it->gshift)) - 1)) * ldc(&it->grp_stride) + lane * 4) * 4); };   // bytes
+  auto slice_steps = [&](const PixItem* it) { return steps + ldc(&it->step_base) + (wave >> ldc(&it->gshift)) * ldc(&it->nkp); };
+  // output quads of a pass owned by this thread: (row, 4 columns) x 2
+  struct Quads { int row[2], col[2]; bool ok[2]; };
+  auto quads_of = [&](const PixItem* it) {
+    Quads q;
+    const bool small = (ldc(&it->flags) & PIF_SMALL) != 0;
+    const int gw = small ? 64 : 32, qshift = ldc(&it->gshift) + (small ? 4 : 3), total = ldc(&it->P_out) << qshift;
 #pragma unroll
-    for (int r = 0; r < PD; ++r) {
-      const PixStep e = ldc_step(st_c + r);
-      asel[r] = e.a_sel;
-      const float* base_ = frag + e.w_off;
-      PIX_LOAD_SLOT(r, base_, off_c);
+    for (int j = 0; j < 2; ++j) {
+      const int idx = tid + j * PNT, idc = idx < total ? idx : total - 1;
+      q.ok[j] = idx < total;
+      q.row[j] = idc >> qshift;
+      q.col[j] = ldc(&it->grp0) * gw + ((idc & ((1 << qshift) - 1)) << 2);
     }
+    return q;
+  };
+  // request the epilogue operands (bias, folded-GroupNorm S and B1) of a pass into a[64 .. 87]
+  auto request_epilogue_operands = [&](const PixItem* it) {
+    const Quads q = quads_of(it);
+    const int npad = ldc(&it->Npad), rst = ldc(&it->rowstride);
+    const float* bias = ldc(&it->bias); const float* gs = ldc(&it->gn_s); const float* gb = ldc(&it->gn_b1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int colc = q.col[j] < npad - 4 ? q.col[j] : npad - 4;
+      const float* pb = bias + colc; const float* ps = gs + (long long)q.row[j] * rst + colc; const float* pg = gb + (long long)q.row[j] * rst + colc;
+      if (j == 0) PIX_ELOAD(pb, ps, pg, 64, 67, 68, 71, 72, 75); else PIX_ELOAD(pb, ps, pg, 76, 79, 80, 83, 84, 87);
+    }
+  };
+  int ci = 0;
+  const PixItem* pc = items;
+  unsigned off_c = lane_off(pc);
+  const PixStep* st_c = slice_steps(pc);
+#pragma unroll
+  for (int r = 0; r < PD; ++r) {
+    const PixStep e = ldc_step(st_c + r);
+    asel[r] = e.a_sel;
+    const float* base_ = frag + e.w_off;
+    PIX_LOAD_SLOT(r, base_, off_c);
   }
+  request_epilogue_operands(pc);
   for (int k = 0; k < count; ++k) {
     const PixOpD& op = ops[k];
     const int kind = ldc(&op.kind);
     if (dbg && b == 0 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();
     if (kind == PIX_STAGE) {
-      const int C4 = op.st_C >> 2;
-      for (int idx = tid; idx < op.st_P * C4; idx += PNT) {
+      const int C4 = ldc(&op.st_C) >> 2, st_P = ldc(&op.st_P), st_ld = ldc(&op.st_ld), st_lds = ldc(&op.st_lds), st_stat = ldc(&op.st_stat);
+      const float* src = ldc(&op.st_src);
+      for (int idx = tid; idx < st_P * C4; idx += PNT) {
         const int c4 = idx % C4, p = idx / C4;
-        const float4 v = *reinterpret_cast<const float4*>(op.st_src + ((long long)p * B + b) * op.st_ld + 4 * c4);
-        *reinterpret_cast<float4*>(lds + op.st_lds + pix_at(4 * c4, p)) = v;
+        const float4 v = *reinterpret_cast<const float4*>(src + ((long long)p * B + b) * st_ld + 4 * c4);
+        *reinterpret_cast<float4*>(lds + st_lds + pix_at(4 * c4, p)) = v;
       }
-      if (op.st_stat >= 0 && tid == 0) {
+      if (st_stat >= 0 && lane == 0) {
         double s = 0.0, qq = 0.0;
-        for (int i = 0; i < op.st_nparts; ++i) { const float2 v = op.st_part[(long long)i * B + b]; s += (double)v.x; qq += (double)v.y; }
-        stat[op.st_stat * 2] = (float)s; stat[op.st_stat * 2 + 1] = (float)qq;
+        if (wave == 0) { const float2* part = ldc(&op.st_part); const int np = ldc(&op.st_nparts); for (int i = 0; i < np; ++i) { const float2 v = part[(long long)i * B + b]; s += (double)v.x; qq += (double)v.y; } }
+        stat[(st_stat * PNW + wave) * 2] = (float)s; stat[(st_stat * PNW + wave) * 2 + 1] = (float)qq;
       }
       __syncthreads();
       continue;
     }
     if (kind == OP_DWCONV7) {
       // depth-wise 7x7 over an image of at most 4x4: the window covers the whole image.  Task = (channel, output row py): its W outputs
-      // need the H x (2 W - 1) weights w[qy - py + 3][d + 3], each loaded once (coalesced over the channels), and the channel's H W inputs.
-      const DwArgs& d = op.dw;
-      const int C = d.C, H = d.H, W = d.W, P = H * W;
+      // need the H x (2 W - 1) weights w[qy - py + 3][d + 3], each loaded once (coalesced over the channels, all issued before the first
+      // is used: dead taps read a clamped address and are masked afterwards), and the channel's H W inputs.
+      const int C = ldc(&op.dw.C), H = ldc(&op.dw.H), W = ldc(&op.dw.W), ldo = ldc(&op.dw.ldo), in_lds = ldc(&op.in_lds), out_lds = ldc(&op.out_lds);
+      const float* dw_w = ldc(&op.dw.w); const float* dw_bias = ldc(&op.dw.bias); const float* dw_cond = ldc(&op.dw.cond);
+      float* dw_out = ldc(&op.out_g) ? ldc(&op.dw.out) : nullptr;
+      const float* cond = dw_cond ? (cond_tab && ldc(&op.dw.ctl) ? cond_tab + ldc(&op.dw.cond_col) : dw_cond + (long long)b * ldc(&op.dw.cond_ld)) : nullptr;
       float s = 0.f, qq = 0.f;
       for (int task = tid; task < C * H; task += PNT) {
         const int c = task % C, py = task / C;
         float wv[4][7], xv[4][4], acc[4];
-        const float bi = d.bias[c] + (d.cond ? dw_cond_row(d, b)[c] : 0.f);
+        float bi = dw_bias[c];
+        const float cv = cond ? cond[c] : 0.f;
 #pragma unroll
         for (int qy = 0; qy < 4; ++qy)
 #pragma unroll
           for (int dx = 0; dx < 7; ++dx) {
-            const bool live = qy < H && dx >= 4 - W && dx <= 2 + W;
-            wv[qy][dx] = live ? d.w[((qy - py + 3) * 7 + dx) * C + c] : 0.f;
+            const int qyc = qy < H ? qy : H - 1;
+            wv[qy][dx] = dw_w[((qyc - py + 3) * 7 + dx) * C + c];
           }
 #pragma unroll
         for (int qy = 0; qy < 4; ++qy)
 #pragma unroll
-          for (int qx = 0; qx < 4; ++qx) xv[qy][qx] = (qy < H && qx < W) ? lds[op.in_lds + pix_at(c, qy * W + qx)] : 0.f;
+          for (int qx = 0; qx < 4; ++qx) xv[qy][qx] = (qy < H && qx < W) ? lds[in_lds + pix_at(c, qy * W + qx)] : 0.f;      // dead inputs are zeros: their weights do not matter
+        bi += cv;
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
           float a = 0.f;
 #pragma unroll
           for (int qy = 0; qy < 4; ++qy)
 #pragma unroll
-            for (int qx = 0; qx < 4; ++qx) a = fmaf(xv[qy][qx], wv[qy][qx - px + 3], a);     // rows / columns beyond the image carry zeros
+            for (int qx = 0; qx < 4; ++qx) a = fmaf(xv[qy][qx], wv[qy][qx - px + 3], a);
           acc[px] = a + bi;
         }
 #pragma unroll
         for (int px = 0; px < 4; ++px)
           if (px < W) {
             const int p = py * W + px;
-            lds[op.out_lds + pix_at(c, p)] = acc[px];
-            if (op.out_g) d.out[((long long)p * B + b) * d.ldo + c] = acc[px];
+            lds[out_lds + pix_at(c, p)] = acc[px];
+            if (dw_out) dw_out[((long long)p * B + b) * ldo + c] = acc[px];
             s += acc[px]; qq += acc[px] * acc[px];
           }
       }
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m); qq += __shfl_xor(qq, m); }
-      if (lane == 0) { scr[wave] = s; scr[PNW + wave] = qq; }
-      __syncthreads();
-      if (tid == 0) {
-        float ss = 0.f, q2 = 0.f;
-        for (int w = 0; w < PNW; ++w) { ss += scr[w]; q2 += scr[PNW + w]; }
-        if (op.stat_out >= 0) { stat[op.stat_out * 2] = ss; stat[op.stat_out * 2 + 1] = q2; }
-        if (d.stat && op.stat_g) {                       // the plan's layout is one partial per pixel: the whole sum goes to pixel 0
-          d.stat[b] = make_float2(ss, q2);
-          for (int p = 1; p < P; ++p) d.stat[(long long)p * B + b] = make_float2(0.f, 0.f);
+      const int so = ldc(&op.stat_out);
+      if (lane == 0 && so >= 0) { stat[(so * PNW + wave) * 2] = s; stat[(so * PNW + wave) * 2 + 1] = qq; }
+      if (ldc(&op.stat_g)) {                              // the plan's layout is one partial per pixel: the whole sum goes to pixel 0 (debug sub-ranges only)
+        if (lane == 0) { scr[wave] = s; scr[PNW + wave] = qq; }
+        __syncthreads();
+        if (tid == 0) {
+          float ss = 0.f, q2 = 0.f;
+          for (int w = 0; w < PNW; ++w) { ss += scr[w]; q2 += scr[PNW + w]; }
+          float2* dst = ldc(&op.dw.stat);
+          dst[b] = make_float2(ss, q2);
+          for (int p = 1; p < H * W; ++p) dst[(long long)p * B + b] = make_float2(0.f, 0.f);
         }
       }
       __syncthreads();
       continue;
     }
     if (kind == OP_GN_RES) {
-      const GnResArgs& gr = op.gr;
-      const float su = stat[op.gn_stat * 2], sq = stat[op.gn_stat * 2 + 1];
-      const double mean_d = (double)su * (double)gr.inv_count;
-      double var = (double)sq * (double)gr.inv_count - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
+      float su, sq;
+      stat_sum(ldc(&op.gn_stat), &su, &sq);
+      const float inv_count = ldc(&op.gr.inv_count);
+      const double mean_d = (double)su * (double)inv_count;
+      double var = (double)sq * (double)inv_count - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
       const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + 1e-5));
-      const int C4 = gr.C >> 2;
-      for (int idx = tid; idx < gr.P * C4; idx += PNT) {
+      const int C4 = ldc(&op.gr.C) >> 2, P = ldc(&op.gr.P), ldo = ldc(&op.gr.ldo), in_lds = ldc(&op.in_lds), x_lds = ldc(&op.x_lds), out_lds = ldc(&op.out_lds);
+      const float* gamma = ldc(&op.gr.gamma); const float* beta = ldc(&op.gr.beta);
+      float* gout = ldc(&op.out_g) ? ldc(&op.gr.out) : nullptr;
+      for (int idx = tid; idx < P * C4; idx += PNT) {
         const int c4 = idx % C4, p = idx / C4;
-        const float4 u = *reinterpret_cast<const float4*>(lds + op.in_lds + pix_at(4 * c4, p)), x = *reinterpret_cast<const float4*>(lds + op.x_lds + pix_at(4 * c4, p));
-        const float4 ga = *reinterpret_cast<const float4*>(gr.gamma + 4 * c4), be = *reinterpret_cast<const float4*>(gr.beta + 4 * c4);
+        const float4 u = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(4 * c4, p)), x = *reinterpret_cast<const float4*>(lds + x_lds + pix_at(4 * c4, p));
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4), be = *reinterpret_cast<const float4*>(beta + 4 * c4);
         float4 y;
         y.x = ((u.x - mean) * rstd) * ga.x + be.x + x.x; y.y = ((u.y - mean) * rstd) * ga.y + be.y + x.y;
         y.z = ((u.z - mean) * rstd) * ga.z + be.z + x.z; y.w = ((u.w - mean) * rstd) * ga.w + be.w + x.w;
-        *reinterpret_cast<float4*>(lds + op.out_lds + pix_at(4 * c4, p)) = y;
-        if (op.out_g) *reinterpret_cast<float4*>(gr.out + ((long long)p * B + b) * gr.ldo + 4 * c4) = y;
+        *reinterpret_cast<float4*>(lds + out_lds + pix_at(4 * c4, p)) = y;
+        if (gout) *reinterpret_cast<float4*>(gout + ((long long)p * B + b) * ldo + 4 * c4) = y;
       }
       __syncthreads();
       continue;
     }
     if (kind == OP_LINATTN) {
       // LinearAttention core (unet_model.py:169-175) of one sample: n <= 16 positions, heads x 32 channels; q | k | v in one slab
-      const AttnArgs& a = op.at;
-      const int n = a.n, hd = a.heads * 32;
+      const int n = ldc(&op.at.n), heads = ldc(&op.at.heads), hd = heads * 32, in_lds = ldc(&op.in_lds), out_lds = ldc(&op.out_lds), aldo = ldc(&op.at.ldo);
+      const float scale = ldc(&op.at.scale);
+      float* aout = ldc(&op.out_g) ? ldc(&op.at.out) : nullptr;
       if (tid < hd) {                                    // k: softmax over the positions, per channel
         float m = -INFINITY;
-        for (int p = 0; p < n; ++p) m = fmaxf(m, lds[op.in_lds + pix_at(hd + tid, p)]);
+        for (int p = 0; p < n; ++p) m = fmaxf(m, lds[in_lds + pix_at(hd + tid, p)]);
         float z = 0.f;
-        for (int p = 0; p < n; ++p) { const float e = expf(lds[op.in_lds + pix_at(hd + tid, p)] - m); lds[op.in_lds + pix_at(hd + tid, p)] = e; z += e; }
+        for (int p = 0; p < n; ++p) { const float e = expf(lds[in_lds + pix_at(hd + tid, p)] - m); lds[in_lds + pix_at(hd + tid, p)] = e; z += e; }
         const float inv = 1.0f / z;
-        for (int p = 0; p < n; ++p) lds[op.in_lds + pix_at(hd + tid, p)] *= inv;
-      } else if (tid >= 256 && tid < 256 + n * a.heads) {   // q: softmax over the head's channels, per position; scaled
-        const int t = tid - 256, p = t / a.heads, h = t - p * a.heads;
+        for (int p = 0; p < n; ++p) lds[in_lds + pix_at(hd + tid, p)] *= inv;
+      } else if (tid >= 256 && tid < 256 + n * heads) {   // q: softmax over the head's channels, per position; scaled
+        const int t = tid - 256, p = t / heads, h = t - p * heads;
         float m = -INFINITY;
-        for (int dd = 0; dd < 32; ++dd) m = fmaxf(m, lds[op.in_lds + pix_at(h * 32 + dd, p)]);
+        for (int dd = 0; dd < 32; ++dd) m = fmaxf(m, lds[in_lds + pix_at(h * 32 + dd, p)]);
         float z = 0.f;
-        for (int dd = 0; dd < 32; ++dd) { const float e = expf(lds[op.in_lds + pix_at(h * 32 + dd, p)] - m); lds[op.in_lds + pix_at(h * 32 + dd, p)] = e; z += e; }
-        const float inv = a.scale / z;
-        for (int dd = 0; dd < 32; ++dd) lds[op.in_lds + pix_at(h * 32 + dd, p)] *= inv;
+        for (int dd = 0; dd < 32; ++dd) { const float e = expf(lds[in_lds + pix_at(h * 32 + dd, p)] - m); lds[in_lds + pix_at(h * 32 + dd, p)] = e; z += e; }
+        const float inv = scale / z;
+        for (int dd = 0; dd < 32; ++dd) lds[in_lds + pix_at(h * 32 + dd, p)] *= inv;
       }
       __syncthreads();
       // context[h][d][e] = sum_p k[p][h, d] v[p][h, e]: thread = (h, d, 8 consecutive e)
-      for (int t = tid; t < a.heads * 32 * 4; t += PNT) {
+      for (int t = tid; t < heads * 32 * 4; t += PNT) {
         const int h = t >> 7, dd = (t >> 2) & 31, e0 = (t & 3) * 8;
         float cx[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) cx[e] = 0.f;
         for (int p = 0; p < n; ++p) {
-          const float kv = lds[op.in_lds + pix_at(hd + h * 32 + dd, p)];
-          const float4 v0 = *reinterpret_cast<const float4*>(lds + op.in_lds + pix_at(2 * hd + h * 32 + e0, p)), v1 = *reinterpret_cast<const float4*>(lds + op.in_lds + pix_at(2 * hd + h * 32 + e0 + 4, p));
+          const float kv = lds[in_lds + pix_at(hd + h * 32 + dd, p)];
+          const float4 v0 = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(2 * hd + h * 32 + e0, p)), v1 = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(2 * hd + h * 32 + e0 + 4, p));
           cx[0] = fmaf(kv, v0.x, cx[0]); cx[1] = fmaf(kv, v0.y, cx[1]); cx[2] = fmaf(kv, v0.z, cx[2]); cx[3] = fmaf(kv, v0.w, cx[3]);
           cx[4] = fmaf(kv, v1.x, cx[4]); cx[5] = fmaf(kv, v1.y, cx[5]); cx[6] = fmaf(kv, v1.z, cx[6]); cx[7] = fmaf(kv, v1.w, cx[7]);
         }
@@ -328,53 +375,37 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       for (int t = tid; t < n * hd; t += PNT) {
         const int ch = t % hd, p = t / hd, h = ch >> 5, e = ch & 31;
         float o = 0.f;
-        for (int dd = 0; dd < 32; ++dd) o = fmaf(lds[op.in_lds + pix_at(h * 32 + dd, p)], scr[(h * 32 + dd) * 33 + e], o);
-        lds[op.out_lds + pix_at(ch, p)] = o;
-        if (op.out_g) a.out[((long long)p * B + b) * a.ldo + ch] = o;
+        for (int dd = 0; dd < 32; ++dd) o = fmaf(lds[in_lds + pix_at(h * 32 + dd, p)], scr[(h * 32 + dd) * 33 + e], o);
+        lds[out_lds + pix_at(ch, p)] = o;
+        if (aout) aout[((long long)p * B + b) * aldo + ch] = o;
       }
       __syncthreads();
       continue;
     }
-    // ---------------------------------------------------------------- GEMM
+    // ---------------------------------------------------------------- GEMM: everything comes from the item table
 #define PSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && ci < 60) dbg[128 + ci * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
-    // every field of the op the GEMM path touches, through scalar loads
-    const int g_nitems = ldc(&op.nitems), g_P_out = ldc(&op.P_out), g_Npad = ldc(&op.Npad), g_nstore = ldc(&op.nstore), g_act = ldc(&op.act), g_ldo = ldc(&op.ldo), g_nblk = ldc(&op.nblk);
-    const int g_gn_stat = ldc(&op.gn_stat), g_stat_out = ldc(&op.stat_out), g_out_lds = ldc(&op.out_lds), g_res_lds = ldc(&op.res_lds), g_rowstride = ldc(&op.gn_rowstride);
-    const int g_res_row[4] = {ldc(&op.res_row[0]), ldc(&op.res_row[1]), ldc(&op.res_row[2]), ldc(&op.res_row[3])};
-    const float* g_bias = ldc(&op.bias); const float* g_gn_s = ldc(&op.gn_s); const float* g_gn_b1 = ldc(&op.gn_b1);
-    float* g_out_g = ldc(&op.out_g); float2* g_stat_g = ldc(&op.stat_g);
-    const bool gn = g_gn_stat >= 0;
-    float mean = 0.f, rstd = 1.f, inv_r = 1.f;
-    if (gn) {
-      const float su = stat[g_gn_stat * 2], sq = stat[g_gn_stat * 2 + 1];
-      const double mean_d = (double)su * (double)ldc(&op.gn_inv);
-      double var = (double)sq * (double)ldc(&op.gn_inv) - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
-      mean = (float)mean_d; rstd = rsqrtf((float)var + 1e-5f); inv_r = sqrtf((float)var + 1e-5f);
-    }
-    const bool scale2 = ldc(&op.scale2) != 0;            // folded GroupNorm + fused source-2 conv: source 2 enters unnormalised (x 1 / rstd, undone by the row scaling)
-    float sacc = 0.f, qacc = 0.f;
+    const int g_nitems = ldc(&op.nitems);
     for (int it = 0; it < g_nitems; ++it) {
       const int ni = ci + 1 < nitems ? ci + 1 : 0;
-      const PixItem nxt = ldc_item(items + ni);
-      const unsigned off_n = lane_off(nxt);
-      const PixStep* st_n = slice_steps(nxt);
-      const bool small = cur.small != 0;
-      // output quads of this thread (row, 4 columns) and their epilogue operands, requested before the K loop
-      const int gw = small ? 64 : 32, qshift = cur.gshift + (small ? 4 : 3), total = g_P_out << qshift;
-      int e_row[2], e_col[2]; bool e_ok[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int idx = tid + q * PNT, idc = idx < total ? idx : total - 1;
-        e_ok[q] = idx < total;
-        e_row[q] = idc >> qshift;
-        e_col[q] = cur.grp0 * gw + ((idc & ((1 << qshift) - 1)) << 2);
-        const int colc = e_col[q] < g_Npad - 4 ? e_col[q] : g_Npad - 4;
-        const float* pb = g_bias + colc; const float* ps = g_gn_s + (long long)e_row[q] * g_rowstride + colc; const float* pg = g_gn_b1 + (long long)e_row[q] * g_rowstride + colc;
-        if (q == 0) PIX_ELOAD(pb, ps, pg, 64, 67, 68, 71, 72, 75); else PIX_ELOAD(pb, ps, pg, 76, 79, 80, 83, 84, 87);
+      const PixItem* pn = items + ni;
+      const unsigned off_n = lane_off(pn);
+      const PixStep* st_n = slice_steps(pn);
+      const int flags = ldc(&pc->flags);
+      const bool small = (flags & PIF_SMALL) != 0, gn = (flags & PIF_GN) != 0, scale2 = (flags & PIF_SCALE2) != 0;
+      float mean = 0.f, rstd = 1.f, inv_r = 1.f;
+      if (gn) {
+        float su, sq;
+        stat_sum(ldc(&pc->gn_stat), &su, &sq);
+        const float ginv = ldc(&pc->gn_inv);
+        const double mean_d = (double)su * (double)ginv;
+        double var = (double)sq * (double)ginv - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
+        mean = (float)mean_d; rstd = rsqrtf((float)var + 1e-5f); inv_r = sqrtf((float)var + 1e-5f);
       }
+      const int g_stat_out = ldc(&pc->stat_out);
+      if ((flags & PIF_FIRST) && g_stat_out >= 0 && lane == 0) { stat[(g_stat_out * PNW + wave) * 2] = 0.f; stat[(g_stat_out * PNW + wave) * 2 + 1] = 0.f; }
       PSTAMP(0);
       f32x4p acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const int nu = cur.nkp / PD;
+      const int nu = ldc(&pc->nkp) / PD;
       if (!small) {
         const int n = lane & 15, g = lane >> 4;
         int rs = rtab[((asel[0] >> 16) & 0x7fff) * 16 + n];
@@ -442,59 +473,57 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       }
       __syncthreads();
       PSTAMP(2);
-      // epilogue: operands out of the AGPRs (everything but the 16 loads just issued for the next item has landed)
+      // epilogue: operands out of the AGPRs (everything but the 16 loads just issued for the next pass has landed)
       {
         f32x4p eb[2], es[2], eg[2];
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         PIX_EREAD4(eb[0], 64, 65, 66, 67); PIX_EREAD4(es[0], 68, 69, 70, 71); PIX_EREAD4(eg[0], 72, 73, 74, 75);
         PIX_EREAD4(eb[1], 76, 77, 78, 79); PIX_EREAD4(es[1], 80, 81, 82, 83); PIX_EREAD4(eg[1], 84, 85, 86, 87);
-        const int groups = 1 << cur.gshift, ksplit = 1 << cur.kshift;
+        request_epilogue_operands(pn);                     // a[64 .. 87] are free again: the next pass's operands fly under this epilogue and its K loop
+        const Quads q = quads_of(pc);
+        const int gw = small ? 64 : 32, gshift = ldc(&pc->gshift), groups = 1 << gshift, ksplit = 1 << ldc(&pc->kshift), grp0 = ldc(&pc->grp0);
+        const int nstore = ldc(&pc->nstore), act = ldc(&pc->act), out_lds = ldc(&pc->out_lds), res_lds = ldc(&pc->res_lds), ldo = ldc(&pc->ldo);
+        const int res_row[4] = {ldc(&pc->res_row[0]), ldc(&pc->res_row[1]), ldc(&pc->res_row[2]), ldc(&pc->res_row[3])};
+        float* out_g = ldc(&pc->out_g); float2* stat_g = ldc(&pc->stat_g);
+        float sacc = 0.f, qacc = 0.f;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int row = e_row[q], col = e_col[q];
-          const int cw = col - cur.grp0 * gw, grp = small ? cw >> 6 : cw >> 5, sub = cw & (gw - 1);
+        for (int j = 0; j < 2; ++j) {
+          const int row = q.row[j], col = q.col[j];
+          const int cw = col - grp0 * gw, grp = small ? cw >> 6 : cw >> 5, sub = cw & (gw - 1);
           f32x4p t = {0.f, 0.f, 0.f, 0.f};
           for (int sl = 0; sl < ksplit; ++sl) t += *reinterpret_cast<const f32x4p*>(red + (sl * groups + grp) * 512 + row * gw + sub);
-          const bool ok = e_ok[q] && col < g_nstore;
+          const bool ok = q.ok[j] && col < nstore;
           f32x4p o = {0.f, 0.f, 0.f, 0.f};
           if (ok) {
-            if (gn) t = t * rstd + (eg[q] - (mean * rstd) * es[q]);
-            t += eb[q];
-            if (g_res_lds >= 0) t += *reinterpret_cast<const f32x4p*>(lds + g_res_lds + pix_at(col, sbyte(g_res_row, row)));
+            if (gn) t = t * rstd + (eg[j] - (mean * rstd) * es[j]);
+            t += eb[j];
+            if (res_lds >= 0) t += *reinterpret_cast<const f32x4p*>(lds + res_lds + pix_at(col, sbyte(res_row, row)));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pix_act(g_act, t[e]);
-            if (g_out_lds >= 0) *reinterpret_cast<f32x4p*>(lds + g_out_lds + pix_at(col, row)) = o;
-            if (g_out_g) *reinterpret_cast<f32x4p*>(g_out_g + ((long long)row * B + b) * g_ldo + col) = o;
+            for (int e = 0; e < 4; ++e) o[e] = pix_act(act, t[e]);
+            if (out_lds >= 0) *reinterpret_cast<f32x4p*>(lds + out_lds + pix_at(col, row)) = o;
+            if (out_g) *reinterpret_cast<f32x4p*>(out_g + ((long long)row * B + b) * ldo + col) = o;
             sacc += o[0] + o[1] + o[2] + o[3]; qacc += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
           }
-          if (g_stat_g) {                                  // the plan's partial layout: one (sum, sumsq) per (pixel, 32-column block) = 8 consecutive threads
+          if (stat_g) {                                    // the plan's partial layout: one (sum, sumsq) per (pixel, 32-column block) = 8 consecutive threads
             float s32 = o[0] + o[1] + o[2] + o[3], q32 = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
 #pragma unroll
             for (int m = 1; m < 8; m <<= 1) { s32 += __shfl_xor(s32, m); q32 += __shfl_xor(q32, m); }
-            const int nbk = col >> 5;
-            if ((tid & 7) == 0 && e_ok[q] && nbk < g_nblk) g_stat_g[((long long)row * g_nblk + nbk) * B + b] = make_float2(s32, q32);
+            const int nbk = col >> 5, nblk = (nstore + 31) >> 5;
+            if ((tid & 7) == 0 && q.ok[j] && nbk < nblk) stat_g[((long long)row * nblk + nbk) * B + b] = make_float2(s32, q32);
           }
         }
-      }
-      __syncthreads();                                    // red is reused; the output slab is complete
-      PSTAMP(3);
-      cur = nxt; off_c = off_n; st_c = st_n; ci = ni;
-    }
-    if (g_stat_out >= 0) {
-      float ss = sacc, q2 = qacc;
+        if (g_stat_out >= 0) {                             // this wave's share of the output statistics, added to its own partial (passes of one op accumulate)
 #pragma unroll
-      for (int m = 1; m < 64; m <<= 1) { ss += __shfl_xor(ss, m); q2 += __shfl_xor(q2, m); }
-      if (lane == 0) { scr[wave] = ss; scr[PNW + wave] = q2; }
-      __syncthreads();
-      if (tid == 0) {
-        float a0 = 0.f, a1 = 0.f;
-        for (int w = 0; w < PNW; ++w) { a0 += scr[w]; a1 += scr[PNW + w]; }
-        stat[g_stat_out * 2] = a0; stat[g_stat_out * 2 + 1] = a1;
+          for (int m = 1; m < 64; m <<= 1) { sacc += __shfl_xor(sacc, m); qacc += __shfl_xor(qacc, m); }
+          if (lane == 0) { stat[(g_stat_out * PNW + wave) * 2] += sacc; stat[(g_stat_out * PNW + wave) * 2 + 1] += qacc; }
+        }
       }
-      __syncthreads();
+      __syncthreads();                                    // red is reused; the output slab and the statistics are complete
+      PSTAMP(3);
+      pc = pn; off_c = off_n; st_c = st_n; ci = ni;
     }
   }
-  // the loads issued for the wrapped-around "next" item must land before the wave ends
+  // the loads issued for the wrapped-around "next" pass must land before the wave ends
   asm volatile("s_waitcnt vmcnt(0)" ::: PIX_CLOB_0, PIX_CLOB_1, PIX_CLOB_2, PIX_CLOB_3, PIX_CLOB_E);
   if (dbg && b == 0 && tid == 0) dbg[count] = __builtin_amdgcn_s_memtime();
 }
@@ -631,6 +660,7 @@ struct PBuilder {
   PixOpD stage_op(const PSlot& s) {
     PixOpD d{}; d.kind = PIX_STAGE;
     d.st_src = dp.ws + s.base; d.st_ld = s.ld; d.st_C = s.ld; d.st_P = s.P; d.st_lds = s.lds; d.st_stat = -1;
+    d.gn_stat = d.stat_out = -1;
     return d;
   }
   // An op that writes only PART of a buffer (one half of a skip concatenation) while the rest was produced outside the run: the whole
@@ -667,7 +697,7 @@ struct PBuilder {
   }
 };
 
-size_t pix_lds_bytes(int act_floats, int nrowtab) { return sizeof(float) * ((size_t)act_floats + P_RED_F + P_STAT_SLOTS * 2 + P_SCR_F) + (size_t)nrowtab * 16 + 16; }
+size_t pix_lds_bytes(int act_floats, int nrowtab) { return sizeof(float) * ((size_t)act_floats + P_RED_F + P_STAT_SLOTS * PNW * 2 + P_SCR_F) + (size_t)nrowtab * 16 + 16; }
 
 const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, PProgram* out) {
   const Plan& plan = *dp.plan;
@@ -677,8 +707,8 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
       const Op& op = plan.ops[i];
       b.touched.clear();
       PixOpD d{};
-      d.kind = op.kind; d.gn_stat = -1; d.stat_out = -1; d.out_lds = -1; d.res_lds = -1; d.in_lds = -1;
-      d.bias = d.gn_s = d.gn_b1 = st.zero4;
+      d.kind = op.kind; d.gn_stat = -1; d.stat_out = -1; d.out_lds = -1; d.in_lds = -1;
+      size_t item_first = b.items.size();
       if (op.kind == OP_DWCONV7) {
         const DwOp& o = op.dw;
         if (o.in.H > 4 || o.in.W > 4 || o.stat_slabs > 1) return "pixel kernel: depth-wise op outside the supported shapes";
@@ -710,14 +740,19 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         const int a_lds = b.need(g.a, g.gn ? g.gn_part_off : -1, g.gn_nparts);
         int a2_lds = -1;
         if (g.has2) a2_lds = b.need(g.a2);
-        if (g.has_res) d.res_lds = b.need(g.r);
-        d.P_out = P_out; d.Npad = g.Npad; d.nstore = g.out.C; d.act = g.act; d.ldo = g.out.ld;
-        if (g.bias_off >= 0) d.bias = dp.prm + g.bias_off;
-        if (g.gn) { d.gn_stat = b.stat_slot(g.gn_part_off); d.gn_inv = g.gn_inv_count; d.gn_s = dp.prm + g.gn_s_off; d.gn_b1 = dp.prm + g.gn_b1_off; d.gn_rowstride = g.Npad; }
-        d.scale2 = (g.gn && g.has2) ? 1 : 0;
-        d.out_g = dp.ws + g.out.off;
-        d.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out);
-        if (g.stat_off >= 0) { d.stat_out = b.stat_slot(g.stat_off); d.stat_g = reinterpret_cast<float2*>(dp.ws + g.stat_off); d.nblk = (g.out.C + 31) / 32; }
+        PixItem proto{};                                    // the fields every pass of this op shares
+        proto.res_lds = -1;
+        if (g.has_res) proto.res_lds = b.need(g.r);
+        proto.P_out = P_out; proto.Npad = g.Npad; proto.nstore = g.out.C; proto.act = g.act; proto.ldo = g.out.ld;
+        proto.bias = g.bias_off >= 0 ? dp.prm + g.bias_off : st.zero4;
+        proto.gn_s = proto.gn_b1 = st.zero4; proto.gn_stat = -1; proto.stat_out = -1;
+        if (g.gn) { proto.gn_stat = b.stat_slot(g.gn_part_off); proto.gn_inv = g.gn_inv_count; proto.gn_s = dp.prm + g.gn_s_off; proto.gn_b1 = dp.prm + g.gn_b1_off; proto.rowstride = g.Npad; proto.flags |= PIF_GN; }
+        if (g.gn && g.has2) proto.flags |= PIF_SCALE2;
+        if (fo.small) proto.flags |= PIF_SMALL;
+        proto.out_g = dp.ws + g.out.off;
+        proto.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out);
+        d.out_g = proto.out_g;
+        if (g.stat_off >= 0) { proto.stat_out = b.stat_slot(g.stat_off); proto.stat_g = reinterpret_cast<float2*>(dp.ws + g.stat_off); d.stat_g = proto.stat_g; }
         // row tables: one per live tap (+ source 2)
         const int w2 = g.has2 ? g.a2.W : (g.has_res ? g.r.W : 1);
         std::vector<int> tab_of;
@@ -731,18 +766,18 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
           int rows[16];
           for (int r = 0; r < 16; ++r) rows[r] = r < P_out ? ((r / g.Wout) / g.up2) * w2 + ((r % g.Wout) / g.up2) : -1;
           if (g.has2) tab2 = b.add_rowtab(rows);
-          for (int r = 0; r < 16; ++r) set_sbyte(d.res_row, r, rows[r] < 0 ? 0 : rows[r]);
+          for (int r = 0; r < 16; ++r) set_sbyte(proto.res_row, r, rows[r] < 0 ? 0 : rows[r]);
         }
         if (b.rowtab.size() / 16 > 0x7fff) return "pixel kernel: too many row tables";
         // passes and their step tables
         const int kchunk = fo.small ? 1 : 2;               // LDS chunks per K step
-        d.item0 = (int)b.items.size();
+        item_first = b.items.size();
         for (int g0 = 0; g0 < fo.groups;) {
           int grp = 1; while (grp * 2 <= PNW && grp * 2 <= fo.groups - g0) grp *= 2;
           const int ksplit = PNW / grp;
           const int nk = (fo.F + ksplit - 1) / ksplit, nkp = (nk + PD - 1) / PD * PD;
-          PixItem it{};
-          it.step_base = (int)b.steps.size(); it.nkp = nkp; it.grp0 = g0; it.grp_stride = fo.F * 1024; it.small = fo.small ? 1 : 0;
+          PixItem it = proto;
+          it.step_base = (int)b.steps.size(); it.nkp = nkp; it.grp0 = g0; it.grp_stride = fo.F * 1024;
           int sh = 0; while ((1 << sh) < grp) ++sh; it.gshift = sh;
           sh = 0; while ((1 << sh) < ksplit) ++sh; it.kshift = sh;
           for (int sl = 0; sl < ksplit; ++sl)
@@ -755,17 +790,18 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
                 const long long aoff = (s2 ? a2_lds : a_lds) + (long long)dc * kchunk * PCS;
                 if (b.preset && aoff > 0xffff) return "pixel kernel: LDS offset out of the step table's range";      // (the first pass lays the slabs out without reuse)
                 e.w_off = (unsigned)(fo.off + ((long long)g0 * fo.F + f) * 1024);
-                e.a_sel = (unsigned)aoff | ((unsigned)(s2 ? tab2 : tab_of[ti]) << 16) | (s2 ? 0x80000000u : 0u);
+                e.a_sel = (unsigned)(aoff & 0xffff) | ((unsigned)(s2 ? tab2 : tab_of[ti]) << 16) | (s2 ? 0x80000000u : 0u);
               } else {
                 e.w_off = (unsigned)(fo.off + (long long)g0 * fo.F * 1024);
-                e.a_sel = (unsigned)a_lds;                 // row table 0: every row reads zeros
+                e.a_sel = (unsigned)(a_lds & 0xffff);       // row table 0: every row reads zeros
               }
               b.steps.push_back(e);
             }
           b.items.push_back(it);
           g0 += grp;
         }
-        d.nitems = (int)b.items.size() - d.item0;
+        d.nitems = (int)b.items.size() - (int)item_first;
+        b.items[item_first].flags |= PIF_FIRST; b.items.back().flags |= PIF_LAST;
       } else {
         return "pixel kernel: op kind not supported";
       }
@@ -789,9 +825,14 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
           if ((j < first || j >= first + count) && ((plan.ops[j].kind == OP_GEMM && plan.ops[j].g.gn && plan.ops[j].g.gn_part_off == soff) || (plan.ops[j].kind == OP_GN_RES && plan.ops[j].gr.part_off == soff))) stat_outside = true;
         if (count == 1) { outside = true; stat_outside = true; }
         static float dummy_out;                            // non-null marker for the element-wise ops (they store through their own argument blocks)
-        if (op.kind == OP_GEMM) { if (!outside) d.out_g = nullptr; }
-        else d.out_g = outside ? &dummy_out : nullptr;
-        if (!stat_outside) d.stat_g = nullptr; else if (op.kind == OP_DWCONV7) d.stat_g = reinterpret_cast<float2*>(&dummy_out);
+        if (op.kind == OP_GEMM) {
+          for (size_t ii = item_first; ii < b.items.size(); ++ii) { if (!outside) b.items[ii].out_g = nullptr; if (!stat_outside) b.items[ii].stat_g = nullptr; }
+          if (!outside) d.out_g = nullptr;
+          if (!stat_outside) d.stat_g = nullptr;
+        } else {
+          d.out_g = outside ? &dummy_out : nullptr;
+          d.stat_g = (stat_outside && op.kind == OP_DWCONV7) ? reinterpret_cast<float2*>(&dummy_out) : nullptr;
+        }
       }
       if (b.err) return b.err;
       for (int si : b.touched) b.slots[si].t1 = std::max(b.slots[si].t1, (int)b.ops.size());
@@ -837,7 +878,7 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
   if (act_floats > 0xffff) return "pixel kernel: the activations exceed the step table's LDS range";
   if (pix_lds_bytes(act_floats, (int)b.rowtab.size() / 16) > 160 * 1024) return "pixel kernel: the activations do not fit the LDS";
   if (b.items.empty()) {                                   // a run without a GEMM still needs one (never consumed) item for the loader's prologue
-    PixItem it{}; it.step_base = 0; it.nkp = PD; it.grp_stride = 0;
+    PixItem it{}; it.step_base = 0; it.nkp = PD; it.grp_stride = 0; it.P_out = 1; it.Npad = 32; it.bias = it.gn_s = it.gn_b1 = st.zero4;
     b.items.push_back(it);
     for (int j = 0; j < PNW * PD; ++j) b.steps.push_back(PixStep{0u, 0u});
   }
@@ -936,8 +977,8 @@ const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t s
   const dim3 grid(plan.B), block(PNT);
   const size_t ldsb = pix_lds_bytes(p->act_floats, p->n_rowtab);
   if (g_prof_start) hipExtLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, g_prof_start, g_prof_stop, 0, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab,
-                                          dp.pix->d_frag, plan.B, p->act_floats, g_pix_dbg);
-  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab, dp.pix->d_frag, plan.B, p->act_floats, g_pix_dbg);
+                                          dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg);
+  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab, dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg);
   return nullptr;
 }
 
