@@ -11,6 +11,8 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libsbmae_hip.so")
+if os.environ.get("SBM_LIB"):          # A/B measurements of two builds inside ONE gpurun call (boxes differ by a few percent)
+    LIB_PATH = os.path.abspath(os.environ["SBM_LIB"])
 SOURCES = ["plan.cpp", "kernels.hip", "chain.hip", "rowrun.hip", "pixrun.hip", "sampler.hip", "guidance.hip", "fid.hip", "api.hip"]
 HEADERS = ["plan.h", "device.h", os.path.join("..", "..", "include", "sbmae.h")]
 

@@ -105,6 +105,17 @@ template <typename T> __device__ __forceinline__ T ldc(const T* p) {
   if constexpr (sizeof(T) == 4) { const int v = *(const __attribute__((address_space(4))) int*)(unsigned long long)p; T r; __builtin_memcpy(&r, &v, 4); return r; }
   else { const i32x2p v = *(const __attribute__((address_space(4))) i32x2p*)(unsigned long long)p; T r; __builtin_memcpy(&r, &v, 8); return r; }
 }
+// Sum over the 64 lanes without LDS traffic (__shfl_xor is a ds_bpermute per step): quad swaps, half-row and row mirrors by DPP give every lane
+// its 16-lane row's sum; the four row sums are read with v_readlane and added in a fixed order.  Every lane returns the same total.
+__device__ __forceinline__ float wave_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);
+}
 // float offset of channel k of row r inside a slab
 __device__ __forceinline__ int pix_at(int k, int r) { return (k >> 4) * PCS + r * 16 + (k & 15); }
 __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed char)((w[r >> 2] >> (8 * (r & 3))) & 0xff); }
@@ -160,6 +171,77 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
 #define PIX_EREAD4(dst, A0, A1, A2, A3) \
   asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3 \
                : "=v"(dst[0]), "=v"(dst[1]), "=v"(dst[2]), "=v"(dst[3]))
+
+// LinearAttention core (unet_model.py:169-175) of one sample with the position count N a compile-time constant: every loop over positions
+// or head channels is fully unrolled, so its LDS reads are in flight together (with run-time bounds each iteration exposed a full LDS
+// round trip: 9.6 us at 4x4).  q | k | v in one slab of 3 * hd channels; contexts in `scr` ([hd][33]).
+template <int N>
+__device__ __forceinline__ void pix_linattn(float* lds, float* scr, int tid, int in_lds, int out_lds, int heads, float scale, float* aout, int aldo, int B, int b) {
+  const int hd = heads * 32;
+  if (tid < hd) {                                        // k: softmax over the positions, per channel
+    float v[N];
+#pragma unroll
+    for (int p = 0; p < N; ++p) v[p] = lds[in_lds + pix_at(hd + tid, p)];
+    float m = v[0];
+#pragma unroll
+    for (int p = 1; p < N; ++p) m = fmaxf(m, v[p]);
+    float z = 0.f;
+#pragma unroll
+    for (int p = 0; p < N; ++p) { v[p] = expf(v[p] - m); z += v[p]; }
+    const float inv = 1.0f / z;
+#pragma unroll
+    for (int p = 0; p < N; ++p) lds[in_lds + pix_at(hd + tid, p)] = v[p] * inv;
+  } else if (tid >= 256 && tid < 256 + N * heads) {      // q: softmax over the head's 32 channels, per position; scaled
+    const int t = tid - 256, p = t / heads, h = t - p * heads;
+    float v[32];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 x = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p));
+      v[4 * c] = x.x; v[4 * c + 1] = x.y; v[4 * c + 2] = x.z; v[4 * c + 3] = x.w;
+    }
+    float m = v[0];
+#pragma unroll
+    for (int dd = 1; dd < 32; ++dd) m = fmaxf(m, v[dd]);
+    float z = 0.f;
+#pragma unroll
+    for (int dd = 0; dd < 32; ++dd) { v[dd] = expf(v[dd] - m); z += v[dd]; }
+    const float inv = scale / z;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p)) = make_float4(v[4 * c] * inv, v[4 * c + 1] * inv, v[4 * c + 2] * inv, v[4 * c + 3] * inv);
+  }
+  __syncthreads();
+  // context[h][d][e] = sum_p k[p][h, d] v[p][h, e]: thread = (h, d, 8 consecutive e)
+  for (int t = tid; t < heads * 32 * 4; t += PNT) {
+    const int h = t >> 7, dd = (t >> 2) & 31, e0 = (t & 3) * 8;
+    float cx[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cx[e] = 0.f;
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+      const float kv = lds[in_lds + pix_at(hd + h * 32 + dd, p)];
+      const float4 v0 = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(2 * hd + h * 32 + e0, p)), v1 = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(2 * hd + h * 32 + e0 + 4, p));
+      cx[0] = fmaf(kv, v0.x, cx[0]); cx[1] = fmaf(kv, v0.y, cx[1]); cx[2] = fmaf(kv, v0.z, cx[2]); cx[3] = fmaf(kv, v0.w, cx[3]);
+      cx[4] = fmaf(kv, v1.x, cx[4]); cx[5] = fmaf(kv, v1.y, cx[5]); cx[6] = fmaf(kv, v1.z, cx[6]); cx[7] = fmaf(kv, v1.w, cx[7]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) scr[(h * 32 + dd) * 33 + e0 + e] = cx[e];
+  }
+  __syncthreads();
+  // out[p][h, e] = sum_d q[p][h, d] context[h][d][e]: thread = (p, channel); the q row is read as float4s (broadcast within the head)
+  for (int t = tid; t < N * hd; t += PNT) {
+    const int ch = t % hd, p = t / hd, h = ch >> 5, e = ch & 31;
+    float o = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 qv = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p));
+      o = fmaf(qv.x, scr[(h * 32 + 4 * c) * 33 + e], o); o = fmaf(qv.y, scr[(h * 32 + 4 * c + 1) * 33 + e], o);
+      o = fmaf(qv.z, scr[(h * 32 + 4 * c + 2) * 33 + e], o); o = fmaf(qv.w, scr[(h * 32 + 4 * c + 3) * 33 + e], o);
+    }
+    lds[out_lds + pix_at(ch, p)] = o;
+    if (aout) aout[((long long)p * B + b) * aldo + ch] = o;
+  }
+  __syncthreads();
+}
 
 }  // namespace
 
@@ -292,8 +374,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             s += acc[px]; qq += acc[px] * acc[px];
           }
       }
-#pragma unroll
-      for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m); qq += __shfl_xor(qq, m); }
+      s = wave_sum(s); qq = wave_sum(qq);
       const int so = ldc(&op.stat_out);
       if (lane == 0 && so >= 0) { stat[(so * PNW + wave) * 2] = s; stat[(so * PNW + wave) * 2 + 1] = qq; }
       if (ldc(&op.stat_g)) {                              // the plan's layout is one partial per pixel: the whole sum goes to pixel 0 (debug sub-ranges only)
@@ -338,48 +419,11 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       const int n = ldc(&op.at.n), heads = ldc(&op.at.heads), hd = heads * 32, in_lds = ldc(&op.in_lds), out_lds = ldc(&op.out_lds), aldo = ldc(&op.at.ldo);
       const float scale = ldc(&op.at.scale);
       float* aout = ldc(&op.out_g) ? ldc(&op.at.out) : nullptr;
-      if (tid < hd) {                                    // k: softmax over the positions, per channel
-        float m = -INFINITY;
-        for (int p = 0; p < n; ++p) m = fmaxf(m, lds[in_lds + pix_at(hd + tid, p)]);
-        float z = 0.f;
-        for (int p = 0; p < n; ++p) { const float e = expf(lds[in_lds + pix_at(hd + tid, p)] - m); lds[in_lds + pix_at(hd + tid, p)] = e; z += e; }
-        const float inv = 1.0f / z;
-        for (int p = 0; p < n; ++p) lds[in_lds + pix_at(hd + tid, p)] *= inv;
-      } else if (tid >= 256 && tid < 256 + n * heads) {   // q: softmax over the head's channels, per position; scaled
-        const int t = tid - 256, p = t / heads, h = t - p * heads;
-        float m = -INFINITY;
-        for (int dd = 0; dd < 32; ++dd) m = fmaxf(m, lds[in_lds + pix_at(h * 32 + dd, p)]);
-        float z = 0.f;
-        for (int dd = 0; dd < 32; ++dd) { const float e = expf(lds[in_lds + pix_at(h * 32 + dd, p)] - m); lds[in_lds + pix_at(h * 32 + dd, p)] = e; z += e; }
-        const float inv = scale / z;
-        for (int dd = 0; dd < 32; ++dd) lds[in_lds + pix_at(h * 32 + dd, p)] *= inv;
-      }
-      __syncthreads();
-      // context[h][d][e] = sum_p k[p][h, d] v[p][h, e]: thread = (h, d, 8 consecutive e)
-      for (int t = tid; t < heads * 32 * 4; t += PNT) {
-        const int h = t >> 7, dd = (t >> 2) & 31, e0 = (t & 3) * 8;
-        float cx[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cx[e] = 0.f;
-        for (int p = 0; p < n; ++p) {
-          const float kv = lds[in_lds + pix_at(hd + h * 32 + dd, p)];
-          const float4 v0 = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(2 * hd + h * 32 + e0, p)), v1 = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(2 * hd + h * 32 + e0 + 4, p));
-          cx[0] = fmaf(kv, v0.x, cx[0]); cx[1] = fmaf(kv, v0.y, cx[1]); cx[2] = fmaf(kv, v0.z, cx[2]); cx[3] = fmaf(kv, v0.w, cx[3]);
-          cx[4] = fmaf(kv, v1.x, cx[4]); cx[5] = fmaf(kv, v1.y, cx[5]); cx[6] = fmaf(kv, v1.z, cx[6]); cx[7] = fmaf(kv, v1.w, cx[7]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) scr[(h * 32 + dd) * 33 + e0 + e] = cx[e];
-      }
-      __syncthreads();
-      // out[p][h, e] = sum_d q[p][h, d] context[h][d][e]: thread = (p, channel)
-      for (int t = tid; t < n * hd; t += PNT) {
-        const int ch = t % hd, p = t / hd, h = ch >> 5, e = ch & 31;
-        float o = 0.f;
-        for (int dd = 0; dd < 32; ++dd) o = fmaf(lds[in_lds + pix_at(h * 32 + dd, p)], scr[(h * 32 + dd) * 33 + e], o);
-        lds[out_lds + pix_at(ch, p)] = o;
-        if (aout) aout[((long long)p * B + b) * aldo + ch] = o;
-      }
-      __syncthreads();
+      if (n == 16) pix_linattn<16>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
+      else if (n == 4) pix_linattn<4>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
+      else if (n == 1) pix_linattn<1>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
+      else if (n == 2) pix_linattn<2>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
+      else if (n == 8) pix_linattn<8>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
       continue;
     }
     // ---------------------------------------------------------------- GEMM: everything comes from the item table
@@ -513,8 +557,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
           }
         }
         if (g_stat_out >= 0) {                             // this wave's share of the output statistics, added to its own partial (passes of one op accumulate)
-#pragma unroll
-          for (int m = 1; m < 64; m <<= 1) { sacc += __shfl_xor(sacc, m); qacc += __shfl_xor(qacc, m); }
+          sacc = wave_sum(sacc); qacc = wave_sum(qacc);
           if (lane == 0) { stat[(g_stat_out * PNW + wave) * 2] += sacc; stat[(g_stat_out * PNW + wave) * 2 + 1] += qacc; }
         }
       }
@@ -726,7 +769,8 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         d.gr = make_gnres_args(o, dp.prm, dp.ws);
       } else if (op.kind == OP_LINATTN) {
         const AttnOp& o = op.at;
-        if (o.qkv.H * o.qkv.W > 16 || o.dh != 32 || o.heads * 32 > 256 || o.heads * 32 * 33 > P_SCR_F) return "pixel kernel: unsupported attention op";
+        { const int np = o.qkv.H * o.qkv.W;
+          if ((np != 16 && np != 8 && np != 4 && np != 2 && np != 1) || o.dh != 32 || o.heads * 32 > 256 || o.heads * 32 * 33 > P_SCR_F || np * o.heads > 256) return "pixel kernel: unsupported attention op"; }
         d.in_lds = b.need(o.qkv);
         d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out);
         d.at = make_attn_args(o, dp.ws);
