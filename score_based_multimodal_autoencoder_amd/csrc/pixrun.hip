@@ -61,11 +61,11 @@ struct PixItem {                          // one pass of a GEMM: up to 8 column 
   int Npad, nstore, act, ldo;
   int gn_stat, stat_out, out_lds, res_lds; // LDS statistics slots consumed / produced (-1 none), output / residual slabs (-1 none)
   float gn_inv; int rowstride;            // 1 / (channels x pixels) of the GroupNorm; Npad when the folded-GroupNorm tables are per output pixel, else 0
-  int res_row[4];                         // 16 bytes: residual row of output row r
-  int pad0, pad1;
+  int res_row[4];                         // 16 bytes: residual row of output row r (outputs of at most 16 rows; 64-row outputs read their own row)
+  int rshift, rg0;                        // 64-row outputs (8x8): log2(row groups of 16 in the pass) and its first row group; 0, 0 otherwise
   const float* bias; const float* gn_s; const float* gn_b1;     // never null: a zero vector stands in
   float* out_g; float2* stat_g;           // workspace copies of the output / its statistics, when something outside the launch reads them
-  long long pad2;
+  int out_sub, res_sub;                   // floats between the four 16-row sub-slabs of a 64-row output / residual tensor
 };
 static_assert(sizeof(PixItem) == 144, "PixItem layout");
 
@@ -74,6 +74,7 @@ struct PixOpD {
   int nitems;                            // GEMM: its passes (consecutive entries of the item table)
   int gn_stat, stat_out;                 // LDS statistics slots consumed / produced, -1 none
   int in_lds, out_lds, x_lds, pad;
+  int in_sub, out_sub, x_sub, st_sub;    // floats between the 16-row sub-slabs of 64-row tensors (8x8)
   float* out_g; float2* stat_g;          // non-null: the result / its statistics also go to the workspace
   DwArgs dw; GnResArgs gr; AttnArgs at;
   const float* st_src; const float2* st_part; int st_ld, st_C, st_P, st_lds, st_stat, st_nparts;
@@ -118,14 +119,22 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 // float offset of channel k of row r inside a slab
 __device__ __forceinline__ int pix_at(int k, int r) { return (k >> 4) * PCS + r * 16 + (k & 15); }
+// ... of a tensor of up to 64 rows: four 17-row sub-slabs (rows 16 s .. 16 s + 15 in sub-slab s), `sub` floats apart -- so every chunk keeps
+// its own zero row and the GEMM's row gather stays one table look-up whatever the resolution
+__device__ __forceinline__ int pix_at2(int k, int r, int sub) { return (r >> 4) * sub + (k >> 4) * PCS + (r & 15) * 16 + (k & 15); }
 __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed char)((w[r >> 2] >> (8 * (r & 3))) & 0xff); }
 
-// ---- the weight ring: AGPRs a[16 r .. 16 r + 15] = slot r (four dwordx4 of one step); epilogue operands: a[64 .. 87] ----
-#define PIX_CLOB_0 "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15"
-#define PIX_CLOB_1 "a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31"
-#define PIX_CLOB_2 "a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47"
-#define PIX_CLOB_3 "a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63"
-#define PIX_CLOB_E "a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87"
+// ---- the weight ring: AGPRs.  With any AGPR in use hipcc splits the 256 registers of a 2-waves-per-SIMD kernel 128 / 128 (no attribute of
+// this LLVM moves that line), and past 128 VGPRs it SPILLS INTO AGPRs -- lowest free index first.  Between two asm statements nothing tells it
+// that the ring is live (clobber lists only protect values that live ACROSS a statement), and a first version with the ring at a0.. had slot 0
+// overwritten by spills inside the depth-wise op: wrong first K steps, no fault, no message.  So the ring sits at the TOP of the AGPR half
+// (a40 .. a127: slot r = a[40 + 16 r ..], epilogue operands a[104 .. 127]), a0 .. a39 are left to the compiler, and the build audit
+// (tests/test_host_api.py::test_pixel_kernel_register_audit) fails when a compiler-generated instruction names a40 or above.
+#define PIX_CLOB_0 "a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55"
+#define PIX_CLOB_1 "a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71"
+#define PIX_CLOB_2 "a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87"
+#define PIX_CLOB_3 "a88","a89","a90","a91","a92","a93","a94","a95","a96","a97","a98","a99","a100","a101","a102","a103"
+#define PIX_CLOB_E "a104","a105","a106","a107","a108","a109","a110","a111","a112","a113","a114","a115","a116","a117","a118","a119","a120","a121","a122","a123","a124","a125","a126","a127"
 #define PIX_RING_LOAD(voff, base, A0, A3, A4, A7, A8, A11, A12, A15, CLOB) \
   asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, %1\n\t" \
                "global_load_dwordx4 a[" #A4 ":" #A7 "], %0, %1 offset:1024\n\t" \
@@ -133,10 +142,10 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
                "global_load_dwordx4 a[" #A12 ":" #A15 "], %0, %1 offset:3072" \
                :: "v"(voff), "s"(base) : CLOB)
 #define PIX_LOAD_SLOT(r, base_, off) do { \
-    if ((r) == 0) PIX_RING_LOAD(off, base_, 0, 3, 4, 7, 8, 11, 12, 15, PIX_CLOB_0); \
-    else if ((r) == 1) PIX_RING_LOAD(off, base_, 16, 19, 20, 23, 24, 27, 28, 31, PIX_CLOB_1); \
-    else if ((r) == 2) PIX_RING_LOAD(off, base_, 32, 35, 36, 39, 40, 43, 44, 47, PIX_CLOB_2); \
-    else PIX_RING_LOAD(off, base_, 48, 51, 52, 55, 56, 59, 60, 63, PIX_CLOB_3); } while (0)
+    if ((r) == 0) PIX_RING_LOAD(off, base_, 40, 43, 44, 47, 48, 51, 52, 55, PIX_CLOB_0); \
+    else if ((r) == 1) PIX_RING_LOAD(off, base_, 56, 59, 60, 63, 64, 67, 68, 71, PIX_CLOB_1); \
+    else if ((r) == 2) PIX_RING_LOAD(off, base_, 72, 75, 76, 79, 80, 83, 84, 87, PIX_CLOB_2); \
+    else PIX_RING_LOAD(off, base_, 88, 91, 92, 95, 96, 99, 100, 103, PIX_CLOB_3); } while (0)
 // vmcnt(12): the three other slots' loads (12) are always issued behind a slot's own four before it is consumed again -- the loader never
 // skips a step -- and anything else in flight (epilogue operands, stores, the compiler's own loads) only makes the wait stricter.
 #define PIX_MF16(ACC, A, B) "v_mfma_f32_16x16x4_f32 " ACC ", " A ", a" #B ", " ACC "\n\t"
@@ -146,10 +155,10 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
                PIX_MF16("%0", "%6", B8) PIX_MF16("%1", "%6", B12) PIX_MF16("%0", "%7", B9) PIX_MF16("%1", "%7", B13) PIX_MF16("%0", "%8", B10) PIX_MF16("%1", "%8", B14) PIX_MF16("%0", "%9", B11) "v_mfma_f32_16x16x4_f32 %1, %9, a" #B15 ", %1" \
                : "+v"(acc0), "+v"(acc1) : "v"(a0[0]), "v"(a0[1]), "v"(a0[2]), "v"(a0[3]), "v"(a1[0]), "v"(a1[1]), "v"(a1[2]), "v"(a1[3]))
 #define PIX_MFMA16_SLOT(r, a0, a1) do { \
-    if ((r) == 0) PIX_MFMA16(acc0, acc1, a0, a1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15); \
-    else if ((r) == 1) PIX_MFMA16(acc0, acc1, a0, a1, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31); \
-    else if ((r) == 2) PIX_MFMA16(acc0, acc1, a0, a1, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47); \
-    else PIX_MFMA16(acc0, acc1, a0, a1, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63); } while (0)
+    if ((r) == 0) PIX_MFMA16(acc0, acc1, a0, a1, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55); \
+    else if ((r) == 1) PIX_MFMA16(acc0, acc1, a0, a1, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71); \
+    else if ((r) == 2) PIX_MFMA16(acc0, acc1, a0, a1, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87); \
+    else PIX_MFMA16(acc0, acc1, a0, a1, 88, 89, 90, 91, 92, 93, 94, 95, 96, 97, 98, 99, 100, 101, 102, 103); } while (0)
 #define PIX_MF4(ACC, A, B) "v_mfma_f32_4x4x1_16b_f32 " ACC ", " A ", a" #B ", " ACC "\n\t"
 #define PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, B0, B1, B2, B3, B4, B5, B6, B7, B8, B9, B10, B11, B12, B13, B14, B15) \
   asm volatile("s_waitcnt vmcnt(12)\n\t" \
@@ -158,10 +167,10 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
                : "+v"(acc0), "+v"(acc1) : "v"(q0[0]), "v"(q0[1]), "v"(q0[2]), "v"(q0[3]), "v"(q1[0]), "v"(q1[1]), "v"(q1[2]), "v"(q1[3]), \
                  "v"(q2[0]), "v"(q2[1]), "v"(q2[2]), "v"(q2[3]), "v"(q3[0]), "v"(q3[1]), "v"(q3[2]), "v"(q3[3]))
 #define PIX_MFMA4_SLOT(r) do { \
-    if ((r) == 0) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15); \
-    else if ((r) == 1) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31); \
-    else if ((r) == 2) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47); \
-    else PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63); } while (0)
+    if ((r) == 0) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55); \
+    else if ((r) == 1) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71); \
+    else if ((r) == 2) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87); \
+    else PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 88, 89, 90, 91, 92, 93, 94, 95, 96, 97, 98, 99, 100, 101, 102, 103); } while (0)
 // epilogue operands of one output quad: bias, folded-GroupNorm S and B1 (three dwordx4) into a[BASE .. BASE + 11]
 #define PIX_ELOAD(pb, ps, pg, A0, A3, A4, A7, A8, A11) \
   asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off\n\t" \
@@ -177,6 +186,8 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
 // round trip: 9.6 us at 4x4).  q | k | v in one slab of 3 * hd channels; contexts in `scr` ([hd][33]).
 template <int N>
 __device__ __forceinline__ void pix_linattn(float* lds, float* scr, int tid, int in_lds, int out_lds, int heads, float scale, float* aout, int aldo, int B, int b) {
+  // Register budget: this kernel must stay under 128 VGPRs -- past that hipcc spills into AGPRs, which hold the weight ring (see the
+  // build audit in tests/test_host_api.py) -- so the unrolling below is bounded (groups of 4 positions / 16 channels in flight).
   const int hd = heads * 32;
   if (tid < hd) {                                        // k: softmax over the positions, per channel
     float v[N];
@@ -191,23 +202,29 @@ __device__ __forceinline__ void pix_linattn(float* lds, float* scr, int tid, int
     const float inv = 1.0f / z;
 #pragma unroll
     for (int p = 0; p < N; ++p) lds[in_lds + pix_at(hd + tid, p)] = v[p] * inv;
-  } else if (tid >= 256 && tid < 256 + N * heads) {      // q: softmax over the head's 32 channels, per position; scaled
+  } else if (tid >= 256 && tid < 256 + N * heads) {      // q: softmax over the head's 32 channels, per position; scaled (two halves of 16 in registers)
     const int t = tid - 256, p = t / heads, h = t - p * heads;
-    float v[32];
+    float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const float4 x = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p));
-      v[4 * c] = x.x; v[4 * c + 1] = x.y; v[4 * c + 2] = x.z; v[4 * c + 3] = x.w;
+      m = fmaxf(fmaxf(m, fmaxf(x.x, x.y)), fmaxf(x.z, x.w));
     }
-    float m = v[0];
-#pragma unroll
-    for (int dd = 1; dd < 32; ++dd) m = fmaxf(m, v[dd]);
     float z = 0.f;
-#pragma unroll
-    for (int dd = 0; dd < 32; ++dd) { v[dd] = expf(v[dd] - m); z += v[dd]; }
+#pragma unroll 2
+    for (int c = 0; c < 8; ++c) {
+      float4 x = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p));
+      x.x = expf(x.x - m); x.y = expf(x.y - m); x.z = expf(x.z - m); x.w = expf(x.w - m);
+      z += (x.x + x.y) + (x.z + x.w);
+      *reinterpret_cast<float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p)) = x;
+    }
     const float inv = scale / z;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) *reinterpret_cast<float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p)) = make_float4(v[4 * c] * inv, v[4 * c + 1] * inv, v[4 * c + 2] * inv, v[4 * c + 3] * inv);
+#pragma unroll 2
+    for (int c = 0; c < 8; ++c) {
+      float4 x = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p));
+      x.x *= inv; x.y *= inv; x.z *= inv; x.w *= inv;
+      *reinterpret_cast<float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p)) = x;
+    }
   }
   __syncthreads();
   // context[h][d][e] = sum_p k[p][h, d] v[p][h, e]: thread = (h, d, 8 consecutive e)
@@ -216,7 +233,7 @@ __device__ __forceinline__ void pix_linattn(float* lds, float* scr, int tid, int
     float cx[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) cx[e] = 0.f;
-#pragma unroll
+#pragma unroll 4
     for (int p = 0; p < N; ++p) {
       const float kv = lds[in_lds + pix_at(hd + h * 32 + dd, p)];
       const float4 v0 = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(2 * hd + h * 32 + e0, p)), v1 = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(2 * hd + h * 32 + e0 + 4, p));
@@ -231,7 +248,7 @@ __device__ __forceinline__ void pix_linattn(float* lds, float* scr, int tid, int
   for (int t = tid; t < N * hd; t += PNT) {
     const int ch = t % hd, p = t / hd, h = ch >> 5, e = ch & 31;
     float o = 0.f;
-#pragma unroll
+#pragma unroll 4
     for (int c = 0; c < 8; ++c) {
       const float4 qv = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(h * 32 + 4 * c, p));
       o = fmaf(qv.x, scr[(h * 32 + 4 * c) * 33 + e], o); o = fmaf(qv.y, scr[(h * 32 + 4 * c + 1) * 33 + e], o);
@@ -246,13 +263,13 @@ __device__ __forceinline__ void pix_linattn(float* lds, float* scr, int tid, int
 }  // namespace
 
 __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict__ ops, int count, const PixItem* __restrict__ items, int nitems, const PixStep* __restrict__ steps,
-                                                        const unsigned char* __restrict__ rowtab, int nrowtab, const float* __restrict__ frag, const StepCtl* __restrict__ ctl, int B,
+                                                        const unsigned short* __restrict__ rowtab, int nrowtab, const float* __restrict__ frag, const StepCtl* __restrict__ ctl, int B,
                                                         int act_floats, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* red = lds + act_floats;                         // [8 waves][512]: 16 rows x 32 columns, or 4 rows x 64 columns
   float* stat = red + P_RED_F;                           // [slots][8 waves][2]: per-wave partial (sum, sumsq); readers add the eight in wave order
   float* scr = stat + P_STAT_SLOTS * PNW * 2;            // scratch (LinearAttention contexts)
-  unsigned char* rtab = reinterpret_cast<unsigned char*>(scr + P_SCR_F);   // [nrowtab][16]: source row of output row r (16 = the zero row)
+  unsigned short* rtab = reinterpret_cast<unsigned short*>(scr + P_SCR_F);   // [nrowtab][16]: source row of output row r in 16-float units from the slab origin (16 = the zero row)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x;
   for (int i = tid; i < act_floats + P_RED_F; i += PNT) lds[i] = 0.f;
@@ -270,23 +287,26 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
   // ---- loader state (per wave; survives the non-GEMM ops between two GEMMs) ----
   unsigned asel[PD];
   auto lane_off = [&](const PixItem* it) { return (unsigned)(((wave & ((1 << ldc(&it->gshift)) - 1)) * ldc(&it->grp_stride) + lane * 4) * 4); };   // bytes
-  auto slice_steps = [&](const PixItem* it) { return steps + ldc(&it->step_base) + (wave >> ldc(&it->gshift)) * ldc(&it->nkp); };
+  auto slice_steps = [&](const PixItem* it) { return steps + ldc(&it->step_base) + (wave >> (ldc(&it->gshift) + ldc(&it->rshift))) * ldc(&it->nkp); };
   // output quads of a pass owned by this thread: (row, 4 columns) x 2
-  struct Quads { int row[2], col[2]; bool ok[2]; };
+  struct Quads { int row[2], prow[2], col[2]; bool ok[2]; };
   auto quads_of = [&](const PixItem* it) {
     Quads q;
     const bool small = (ldc(&it->flags) & PIF_SMALL) != 0;
-    const int gw = small ? 64 : 32, qshift = ldc(&it->gshift) + (small ? 4 : 3), total = ldc(&it->P_out) << qshift;
+    const int gw = small ? 64 : 32, qshift = ldc(&it->gshift) + (small ? 4 : 3), rshift = ldc(&it->rshift);
+    const int prow = ldc(&it->P_out) < (16 << rshift) ? ldc(&it->P_out) : (16 << rshift);      // rows of the pass
+    const int total = prow << qshift;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int idx = tid + j * PNT, idc = idx < total ? idx : total - 1;
       q.ok[j] = idx < total;
-      q.row[j] = idc >> qshift;
+      q.prow[j] = idc >> qshift;                           // row inside the pass: row group (prow >> 4), row of the unit (prow & 15)
+      q.row[j] = ldc(&it->rg0) * 16 + q.prow[j];
       q.col[j] = ldc(&it->grp0) * gw + ((idc & ((1 << qshift) - 1)) << 2);
     }
     return q;
   };
-  // request the epilogue operands (bias, folded-GroupNorm S and B1) of a pass into a[64 .. 87]
+  // request the epilogue operands (bias, folded-GroupNorm S and B1) of a pass into a[104 .. 127]
   auto request_epilogue_operands = [&](const PixItem* it) {
     const Quads q = quads_of(it);
     const int npad = ldc(&it->Npad), rst = ldc(&it->rowstride);
@@ -295,7 +315,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     for (int j = 0; j < 2; ++j) {
       const int colc = q.col[j] < npad - 4 ? q.col[j] : npad - 4;
       const float* pb = bias + colc; const float* ps = gs + (long long)q.row[j] * rst + colc; const float* pg = gb + (long long)q.row[j] * rst + colc;
-      if (j == 0) PIX_ELOAD(pb, ps, pg, 64, 67, 68, 71, 72, 75); else PIX_ELOAD(pb, ps, pg, 76, 79, 80, 83, 84, 87);
+      if (j == 0) PIX_ELOAD(pb, ps, pg, 104, 107, 108, 111, 112, 115); else PIX_ELOAD(pb, ps, pg, 116, 119, 120, 123, 124, 127);
     }
   };
   int ci = 0;
@@ -315,12 +335,12 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     const int kind = ldc(&op.kind);
     if (dbg && b == 0 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();
     if (kind == PIX_STAGE) {
-      const int C4 = ldc(&op.st_C) >> 2, st_P = ldc(&op.st_P), st_ld = ldc(&op.st_ld), st_lds = ldc(&op.st_lds), st_stat = ldc(&op.st_stat);
+      const int C4 = ldc(&op.st_C) >> 2, st_P = ldc(&op.st_P), st_ld = ldc(&op.st_ld), st_lds = ldc(&op.st_lds), st_stat = ldc(&op.st_stat), st_sub = ldc(&op.st_sub);
       const float* src = ldc(&op.st_src);
       for (int idx = tid; idx < st_P * C4; idx += PNT) {
         const int c4 = idx % C4, p = idx / C4;
         const float4 v = *reinterpret_cast<const float4*>(src + ((long long)p * B + b) * st_ld + 4 * c4);
-        *reinterpret_cast<float4*>(lds + st_lds + pix_at(4 * c4, p)) = v;
+        *reinterpret_cast<float4*>(lds + st_lds + pix_at2(4 * c4, p, st_sub)) = v;
       }
       if (st_stat >= 0 && lane == 0) {
         double s = 0.0, qq = 0.0;
@@ -335,10 +355,48 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       // need the H x (2 W - 1) weights w[qy - py + 3][d + 3], each loaded once (coalesced over the channels, all issued before the first
       // is used: dead taps read a clamped address and are masked afterwards), and the channel's H W inputs.
       const int C = ldc(&op.dw.C), H = ldc(&op.dw.H), W = ldc(&op.dw.W), ldo = ldc(&op.dw.ldo), in_lds = ldc(&op.in_lds), out_lds = ldc(&op.out_lds);
+      const int in_sub = ldc(&op.in_sub), out_sub = ldc(&op.out_sub);
       const float* dw_w = ldc(&op.dw.w); const float* dw_bias = ldc(&op.dw.bias); const float* dw_cond = ldc(&op.dw.cond);
       float* dw_out = ldc(&op.out_g) ? ldc(&op.dw.out) : nullptr;
       const float* cond = dw_cond ? (cond_tab && ldc(&op.dw.ctl) ? cond_tab + ldc(&op.dw.cond_col) : dw_cond + (long long)b * ldc(&op.dw.cond_ld)) : nullptr;
       float s = 0.f, qq = 0.f;
+      if (H == 8 && W == 8) {
+        // 8x8: the 49 x C weights go through LDS (coalesced float4 loads, a handful of registers) -- held in registers, 49 weights per thread
+        // pushed the kernel past 128 VGPRs, and hipcc then SPILLS INTO AGPRs, the weight ring's included (silent corruption; the build
+        // audit in tests/test_host_api.py counts v_accvgpr instructions).  Task = (channel, output row py): 8 outputs from up to 7 rows.
+        for (int i = tid; i < (49 * C) >> 2; i += PNT) *reinterpret_cast<float4*>(scr + 4 * i) = *reinterpret_cast<const float4*>(dw_w + 4 * i);
+        __syncthreads();
+        for (int task = tid; task < C * 8; task += PNT) {
+          const int c = task % C, py = task / C;
+          float acc[8];
+          const float bi = dw_bias[c] + (cond ? cond[c] : 0.f);
+#pragma unroll
+          for (int px = 0; px < 8; ++px) acc[px] = 0.f;
+#pragma unroll
+          for (int ky = 0; ky < 7; ++ky) {
+            const int qy = py + ky - 3;
+            const bool in = qy >= 0 && qy < 8;
+            const int qyc = in ? qy : 0;
+            float xr[8], wr[7];
+#pragma unroll
+            for (int qx = 0; qx < 8; ++qx) { const float v = lds[in_lds + pix_at2(c, qyc * 8 + qx, in_sub)]; xr[qx] = in ? v : 0.f; }
+#pragma unroll
+            for (int kx = 0; kx < 7; ++kx) wr[kx] = scr[(ky * 7 + kx) * C + c];
+#pragma unroll
+            for (int px = 0; px < 8; ++px)
+#pragma unroll
+              for (int kx = 0; kx < 7; ++kx) { const int qx = px + kx - 3; if (qx >= 0 && qx < 8) acc[px] = fmaf(xr[qx], wr[kx], acc[px]); }
+          }
+#pragma unroll
+          for (int px = 0; px < 8; ++px) {
+            const int p = py * 8 + px;
+            const float v = acc[px] + bi;
+            lds[out_lds + pix_at2(c, p, out_sub)] = v;
+            if (dw_out) dw_out[((long long)p * B + b) * ldo + c] = v;
+            s += v; qq += v * v;
+          }
+        }
+      } else {
       for (int task = tid; task < C * H; task += PNT) {
         const int c = task % C, py = task / C;
         float wv[4][7], xv[4][4], acc[4];
@@ -374,15 +432,16 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             s += acc[px]; qq += acc[px] * acc[px];
           }
       }
+      }
       s = wave_sum(s); qq = wave_sum(qq);
       const int so = ldc(&op.stat_out);
       if (lane == 0 && so >= 0) { stat[(so * PNW + wave) * 2] = s; stat[(so * PNW + wave) * 2 + 1] = qq; }
       if (ldc(&op.stat_g)) {                              // the plan's layout is one partial per pixel: the whole sum goes to pixel 0 (debug sub-ranges only)
-        if (lane == 0) { scr[wave] = s; scr[PNW + wave] = qq; }
+        if (lane == 0) { red[wave] = s; red[PNW + wave] = qq; }      // (not scr: at 8x8 it holds the staged weights other waves may still be reading)
         __syncthreads();
         if (tid == 0) {
           float ss = 0.f, q2 = 0.f;
-          for (int w = 0; w < PNW; ++w) { ss += scr[w]; q2 += scr[PNW + w]; }
+          for (int w = 0; w < PNW; ++w) { ss += red[w]; q2 += red[PNW + w]; }
           float2* dst = ldc(&op.dw.stat);
           dst[b] = make_float2(ss, q2);
           for (int p = 1; p < H * W; ++p) dst[(long long)p * B + b] = make_float2(0.f, 0.f);
@@ -399,16 +458,17 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       double var = (double)sq * (double)inv_count - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
       const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + 1e-5));
       const int C4 = ldc(&op.gr.C) >> 2, P = ldc(&op.gr.P), ldo = ldc(&op.gr.ldo), in_lds = ldc(&op.in_lds), x_lds = ldc(&op.x_lds), out_lds = ldc(&op.out_lds);
+      const int in_sub = ldc(&op.in_sub), x_sub = ldc(&op.x_sub), out_sub = ldc(&op.out_sub);
       const float* gamma = ldc(&op.gr.gamma); const float* beta = ldc(&op.gr.beta);
       float* gout = ldc(&op.out_g) ? ldc(&op.gr.out) : nullptr;
       for (int idx = tid; idx < P * C4; idx += PNT) {
         const int c4 = idx % C4, p = idx / C4;
-        const float4 u = *reinterpret_cast<const float4*>(lds + in_lds + pix_at(4 * c4, p)), x = *reinterpret_cast<const float4*>(lds + x_lds + pix_at(4 * c4, p));
+        const float4 u = *reinterpret_cast<const float4*>(lds + in_lds + pix_at2(4 * c4, p, in_sub)), x = *reinterpret_cast<const float4*>(lds + x_lds + pix_at2(4 * c4, p, x_sub));
         const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * c4), be = *reinterpret_cast<const float4*>(beta + 4 * c4);
         float4 y;
         y.x = ((u.x - mean) * rstd) * ga.x + be.x + x.x; y.y = ((u.y - mean) * rstd) * ga.y + be.y + x.y;
         y.z = ((u.z - mean) * rstd) * ga.z + be.z + x.z; y.w = ((u.w - mean) * rstd) * ga.w + be.w + x.w;
-        *reinterpret_cast<float4*>(lds + out_lds + pix_at(4 * c4, p)) = y;
+        *reinterpret_cast<float4*>(lds + out_lds + pix_at2(4 * c4, p, out_sub)) = y;
         if (gout) *reinterpret_cast<float4*>(gout + ((long long)p * B + b) * ldo + 4 * c4) = y;
       }
       __syncthreads();
@@ -420,10 +480,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       const float scale = ldc(&op.at.scale);
       float* aout = ldc(&op.out_g) ? ldc(&op.at.out) : nullptr;
       if (n == 16) pix_linattn<16>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
-      else if (n == 4) pix_linattn<4>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
-      else if (n == 1) pix_linattn<1>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
-      else if (n == 2) pix_linattn<2>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
-      else if (n == 8) pix_linattn<8>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
+      else pix_linattn<4>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
       continue;
     }
     // ---------------------------------------------------------------- GEMM: everything comes from the item table
@@ -451,7 +508,8 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       f32x4p acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const int nu = ldc(&pc->nkp) / PD;
       if (!small) {
-        const int n = lane & 15, g = lane >> 4;
+        const int g = lane >> 4;
+        const int n = (((wave >> ldc(&pc->gshift)) & ((1 << ldc(&pc->rshift)) - 1)) + ldc(&pc->rg0)) * 16 + (lane & 15);     // this lane's output row: row group of the wave's unit x 16 + lane
         int rs = rtab[((asel[0] >> 16) & 0x7fff) * 16 + n];
         const float* ap0 = lds + (asel[0] & 0xffff) + rs * 16 + 4 * g;
         f32x4p a0 = *reinterpret_cast<const f32x4p*>(ap0), a1 = *reinterpret_cast<const f32x4p*>(ap0 + PCS);
@@ -521,11 +579,12 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       {
         f32x4p eb[2], es[2], eg[2];
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        PIX_EREAD4(eb[0], 64, 65, 66, 67); PIX_EREAD4(es[0], 68, 69, 70, 71); PIX_EREAD4(eg[0], 72, 73, 74, 75);
-        PIX_EREAD4(eb[1], 76, 77, 78, 79); PIX_EREAD4(es[1], 80, 81, 82, 83); PIX_EREAD4(eg[1], 84, 85, 86, 87);
-        request_epilogue_operands(pn);                     // a[64 .. 87] are free again: the next pass's operands fly under this epilogue and its K loop
+        PIX_EREAD4(eb[0], 104, 105, 106, 107); PIX_EREAD4(es[0], 108, 109, 110, 111); PIX_EREAD4(eg[0], 112, 113, 114, 115);
+        PIX_EREAD4(eb[1], 116, 117, 118, 119); PIX_EREAD4(es[1], 120, 121, 122, 123); PIX_EREAD4(eg[1], 124, 125, 126, 127);
+        request_epilogue_operands(pn);                     // a[104 .. 127] are free again: the next pass's operands fly under this epilogue and its K loop
         const Quads q = quads_of(pc);
-        const int gw = small ? 64 : 32, gshift = ldc(&pc->gshift), groups = 1 << gshift, ksplit = 1 << ldc(&pc->kshift), grp0 = ldc(&pc->grp0);
+        const int gw = small ? 64 : 32, gshift = ldc(&pc->gshift), ushift = gshift + ldc(&pc->rshift), ksplit = 1 << ldc(&pc->kshift), grp0 = ldc(&pc->grp0);
+        const int out_sub = ldc(&pc->out_sub), res_sub = ldc(&pc->res_sub), P_out = ldc(&pc->P_out);
         const int nstore = ldc(&pc->nstore), act = ldc(&pc->act), out_lds = ldc(&pc->out_lds), res_lds = ldc(&pc->res_lds), ldo = ldc(&pc->ldo);
         const int res_row[4] = {ldc(&pc->res_row[0]), ldc(&pc->res_row[1]), ldc(&pc->res_row[2]), ldc(&pc->res_row[3])};
         float* out_g = ldc(&pc->out_g); float2* stat_g = ldc(&pc->stat_g);
@@ -534,17 +593,18 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         for (int j = 0; j < 2; ++j) {
           const int row = q.row[j], col = q.col[j];
           const int cw = col - grp0 * gw, grp = small ? cw >> 6 : cw >> 5, sub = cw & (gw - 1);
+          const int unit = ((q.prow[j] >> 4) << gshift) | grp;       // the wave (of K slice 0) that owns this output: [column group | row group]
           f32x4p t = {0.f, 0.f, 0.f, 0.f};
-          for (int sl = 0; sl < ksplit; ++sl) t += *reinterpret_cast<const f32x4p*>(red + (sl * groups + grp) * 512 + row * gw + sub);
+          for (int sl = 0; sl < ksplit; ++sl) t += *reinterpret_cast<const f32x4p*>(red + ((sl << ushift) | unit) * 512 + (q.prow[j] & 15) * gw + sub);
           const bool ok = q.ok[j] && col < nstore;
           f32x4p o = {0.f, 0.f, 0.f, 0.f};
           if (ok) {
             if (gn) t = t * rstd + (eg[j] - (mean * rstd) * es[j]);
             t += eb[j];
-            if (res_lds >= 0) t += *reinterpret_cast<const f32x4p*>(lds + res_lds + pix_at(col, sbyte(res_row, row)));
+            if (res_lds >= 0) t += *reinterpret_cast<const f32x4p*>(lds + res_lds + pix_at2(col, P_out > 16 ? row : sbyte(res_row, row & 15), res_sub));
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pix_act(act, t[e]);
-            if (out_lds >= 0) *reinterpret_cast<f32x4p*>(lds + out_lds + pix_at(col, row)) = o;
+            if (out_lds >= 0) *reinterpret_cast<f32x4p*>(lds + out_lds + pix_at2(col, row, out_sub)) = o;
             if (out_g) *reinterpret_cast<f32x4p*>(out_g + ((long long)row * B + b) * ldo + col) = o;
             sacc += o[0] + o[1] + o[2] + o[3]; qacc += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
           }
@@ -576,7 +636,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
 // ------------------------------------------------------------------------------------------------
 namespace {
 
-struct PSlot { long long base; int ld; int P; int lds; int t0, t1; };
+struct PSlot { long long base; int ld; int P; int lds; int t0, t1; };      // tensors of 64 pixels are four 16-row sub-slabs, chunks_of(ld) chunks each
 
 void set_sbyte(int* w, int r, int v) { w[r >> 2] = (w[r >> 2] & ~(0xff << (8 * (r & 3)))) | ((v & 0xff) << (8 * (r & 3))); }
 
@@ -589,7 +649,7 @@ struct PFragOp {                          // fragment-order copy of one GEMM op'
   int ndc = 0, ndc2 = 0;                  // K steps per tap / of source 2
 };
 
-struct PProgram { PixOpD* d_ops = nullptr; PixItem* d_items = nullptr; PixStep* d_steps = nullptr; unsigned char* d_rowtab = nullptr;
+struct PProgram { PixOpD* d_ops = nullptr; PixItem* d_items = nullptr; PixStep* d_steps = nullptr; unsigned short* d_rowtab = nullptr;
                   int n_ops = 0, n_items = 0, n_rowtab = 0, act_floats = 0; std::vector<int> kinds; };
 
 }  // namespace
@@ -613,9 +673,10 @@ bool pix_tap_live(const GemmOp& g, int ky, int kx) {
 
 const char* pix_gemm_supported(const GemmOp& g) {
   const int P_out = g.Hout * g.Wout, P_in = g.a.H * g.a.W;
-  if (P_out > 16 || P_in > 16 || g.a_ext || g.out_nchw || g.w_pix_stride || g.bias_pix_stride || g.a_bcast || g.a_rows) return "pixel kernel: unsupported GEMM op";
+  if ((P_out > 16 && P_out != 64) || (P_in > 16 && P_in != 64) || g.a_ext || g.out_nchw || g.w_pix_stride || g.bias_pix_stride || g.a_bcast || g.a_rows) return "pixel kernel: unsupported GEMM op";
+  if (P_out == 64 && (g.up2 != 1 || (g.has_res && g.r.H * g.r.W != 64) || (g.has2 && g.a2.H * g.a2.W != 64))) return "pixel kernel: a 64-pixel output takes its residual / source 2 at its own resolution only";
   if ((g.Kp & 31) || (g.has2 && (g.Kp2 & 31)) || (g.Npad & 31) || (g.out.C & 3)) return "pixel kernel: K and N must be multiples of 32";
-  if (g.has2 && g.a2.H * g.a2.W > 16) return "pixel kernel: source 2 has more than 16 pixels";
+  if (g.has2 && g.a2.H * g.a2.W > 16 && g.a2.H * g.a2.W != 64) return "pixel kernel: source 2 has an unsupported pixel count";
   return nullptr;
 }
 
@@ -658,7 +719,7 @@ void pack_fragments(const float* prm, const GemmOp& g, PFragOp* fo, std::vector<
 struct PBuilder {
   const Plan& plan; const DevPlan& dp; const PixState& st; int first, count;
   std::vector<PSlot> slots; int act_chunks = 0;
-  std::vector<PixOpD> ops; std::vector<PixItem> items; std::vector<PixStep> steps; std::vector<unsigned char> rowtab;
+  std::vector<PixOpD> ops; std::vector<PixItem> items; std::vector<PixStep> steps; std::vector<unsigned short> rowtab;
   std::map<long long, int> stat_of;
   std::map<int, int> produced;
   const std::vector<PSlot>* preset = nullptr;
@@ -666,6 +727,9 @@ struct PBuilder {
   const char* err = nullptr;
 
   static int chunks_of(int ld) { return (ld + 15) / 16 + 1; }     // + one chunk of slack: K is walked to the weights' padded depth
+  static int nsub_of(int P) { return P > 16 ? 4 : 1; }
+  static int slab_chunks(const PSlot& s) { return nsub_of(s.P) * chunks_of(s.ld); }
+  static int sub_floats(int ld) { return chunks_of(ld) * PCS; }     // floats between the sub-slabs of a 64-pixel tensor
   // LDS float offset of (row 0, channel 0 of the view)
   int slab(const View& v, int* slot_index) {
     const int P = v.H * v.W;
@@ -689,10 +753,11 @@ struct PBuilder {
     }
     PSlot s{base, v.ld, P, act_chunks * PCS, (int)ops.size(), (int)ops.size()};
     if (v.ld & 15) err = "pixel kernel: a tensor's channel pitch is not a multiple of 16";
+    if (P > 16 && P != 64) err = "pixel kernel: tensors of more than 16 pixels must be 8x8";
     if (preset) {
       for (const PSlot& ps : *preset) if (ps.base == base && ps.ld == v.ld && ps.P == P) s.lds = ps.lds;
     } else {
-      act_chunks += chunks_of(s.ld);
+      act_chunks += slab_chunks(s);
     }
     slots.push_back(s);
     touched.push_back((int)slots.size() - 1);
@@ -702,7 +767,7 @@ struct PBuilder {
   }
   PixOpD stage_op(const PSlot& s) {
     PixOpD d{}; d.kind = PIX_STAGE;
-    d.st_src = dp.ws + s.base; d.st_ld = s.ld; d.st_C = s.ld; d.st_P = s.P; d.st_lds = s.lds; d.st_stat = -1;
+    d.st_src = dp.ws + s.base; d.st_ld = s.ld; d.st_C = s.ld; d.st_P = s.P; d.st_lds = s.lds; d.st_stat = -1; d.st_sub = sub_floats(s.ld);
     d.gn_stat = d.stat_out = -1;
     return d;
   }
@@ -733,19 +798,21 @@ struct PBuilder {
     produced[si] = 1;
     return off;
   }
-  int add_rowtab(const int* rows16) {
-    const int idx = (int)rowtab.size() / 16;
-    for (int r = 0; r < 16; ++r) rowtab.push_back((unsigned char)(rows16[r] < 0 ? 16 : rows16[r]));
+  // a row table: source pixel q of output row r (-1: none) -> its row in 16-float units from the source slab's origin (sub-slab q >> 4, row
+  // q & 15 of a 64-pixel source); 16 = the zero row.  `count` = 16 or 64 output rows; returns the table's index in units of 16 entries.
+  int add_rowtab(const int* rows, int count, int src_ld) {
+    const int idx = (int)rowtab.size() / 16, units = chunks_of(src_ld) * 17;
+    for (int r = 0; r < count; ++r) rowtab.push_back((unsigned short)(rows[r] < 0 ? 16 : (rows[r] >> 4) * units + (rows[r] & 15)));
     return idx;
   }
 };
 
-size_t pix_lds_bytes(int act_floats, int nrowtab) { return sizeof(float) * ((size_t)act_floats + P_RED_F + P_STAT_SLOTS * PNW * 2 + P_SCR_F) + (size_t)nrowtab * 16 + 16; }
+size_t pix_lds_bytes(int act_floats, int nrowtab) { return sizeof(float) * ((size_t)act_floats + P_RED_F + P_STAT_SLOTS * PNW * 2 + P_SCR_F) + (size_t)nrowtab * 32 + 16; }
 
 const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, PProgram* out) {
   const Plan& plan = *dp.plan;
   auto fill = [&](PBuilder& b) -> const char* {
-    b.rowtab.assign(16, 16);                              // table 0: every row -> the zero row (no-op steps)
+    b.rowtab.assign(64, 16);                              // table 0 (64 rows): every row -> the zero row (no-op steps)
     for (int i = first; i < first + count; ++i) {
       const Op& op = plan.ops[i];
       b.touched.clear();
@@ -754,23 +821,23 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
       size_t item_first = b.items.size();
       if (op.kind == OP_DWCONV7) {
         const DwOp& o = op.dw;
-        if (o.in.H > 4 || o.in.W > 4 || o.stat_slabs > 1) return "pixel kernel: depth-wise op outside the supported shapes";
-        d.in_lds = b.need(o.in);
-        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out);
+        if (((o.in.H > 4 || o.in.W > 4) && !(o.in.H == 8 && o.in.W == 8 && 49 * o.in.C <= P_SCR_F && (o.in.C & 3) == 0)) || o.stat_slabs > 1) return "pixel kernel: depth-wise op outside the supported shapes";
+        d.in_lds = b.need(o.in); d.in_sub = PBuilder::sub_floats(o.in.ld);
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out); d.out_sub = PBuilder::sub_floats(o.out.ld);
         d.dw = make_dw_args(plan, o, dp.prm, dp.ws, dp.ctl);
         if (o.stat_off >= 0) d.stat_out = b.stat_slot(o.stat_off);
       } else if (op.kind == OP_GN_RES) {
         const GnResOp& o = op.gr;
-        if (o.u.H * o.u.W > 16 || o.out_ext || (o.u.C & 3)) return "pixel kernel: unsupported GroupNorm+residual op";
-        d.in_lds = b.need(o.u, o.part_off, o.nparts);
-        d.x_lds = b.need(o.x);
+        if ((o.u.H * o.u.W > 16 && o.u.H * o.u.W != 64) || o.out_ext || (o.u.C & 3)) return "pixel kernel: unsupported GroupNorm+residual op";
+        d.in_lds = b.need(o.u, o.part_off, o.nparts); d.in_sub = PBuilder::sub_floats(o.u.ld);
+        d.x_lds = b.need(o.x); d.x_sub = PBuilder::sub_floats(o.x.ld);
         d.gn_stat = b.stat_slot(o.part_off);
-        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out);
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out); d.out_sub = PBuilder::sub_floats(o.out.ld);
         d.gr = make_gnres_args(o, dp.prm, dp.ws);
       } else if (op.kind == OP_LINATTN) {
         const AttnOp& o = op.at;
         { const int np = o.qkv.H * o.qkv.W;
-          if ((np != 16 && np != 8 && np != 4 && np != 2 && np != 1) || o.dh != 32 || o.heads * 32 > 256 || o.heads * 32 * 33 > P_SCR_F || np * o.heads > 256) return "pixel kernel: unsupported attention op"; }
+          if ((np != 16 && np != 4) || o.dh != 32 || o.heads * 32 > 256 || o.heads * 32 * 33 > P_SCR_F || np * o.heads > 256) return "pixel kernel: unsupported attention op"; }
         d.in_lds = b.need(o.qkv);
         d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out);
         d.at = make_attn_args(o, dp.ws);
@@ -786,7 +853,8 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         if (g.has2) a2_lds = b.need(g.a2);
         PixItem proto{};                                    // the fields every pass of this op shares
         proto.res_lds = -1;
-        if (g.has_res) proto.res_lds = b.need(g.r);
+        if (g.has_res) { proto.res_lds = b.need(g.r); proto.res_sub = PBuilder::sub_floats(g.r.ld); }
+        proto.out_sub = PBuilder::sub_floats(g.out.ld);
         proto.P_out = P_out; proto.Npad = g.Npad; proto.nstore = g.out.C; proto.act = g.act; proto.ldo = g.out.ld;
         proto.bias = g.bias_off >= 0 ? dp.prm + g.bias_off : st.zero4;
         proto.gn_s = proto.gn_b1 = st.zero4; proto.gn_stat = -1; proto.stat_out = -1;
@@ -797,51 +865,58 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         proto.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out);
         d.out_g = proto.out_g;
         if (g.stat_off >= 0) { proto.stat_out = b.stat_slot(g.stat_off); proto.stat_g = reinterpret_cast<float2*>(dp.ws + g.stat_off); d.stat_g = proto.stat_g; }
-        // row tables: one per live tap (+ source 2)
+        // row tables: one per live tap (+ source 2), 16 or 64 output rows
         const int w2 = g.has2 ? g.a2.W : (g.has_res ? g.r.W : 1);
+        const int nrows = P_out > 16 ? 64 : 16;
         std::vector<int> tab_of;
         for (int tp : fo.taps) {
-          int rows[16];
-          for (int r = 0; r < 16; ++r) rows[r] = r < P_out ? tap_source_pixel(r / g.Wout, r % g.Wout, tp / g.KW, tp % g.KW, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W) : -1;
-          tab_of.push_back(b.add_rowtab(rows));
+          int rows[64];
+          for (int r = 0; r < nrows; ++r) rows[r] = r < P_out ? tap_source_pixel(r / g.Wout, r % g.Wout, tp / g.KW, tp % g.KW, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W) : -1;
+          tab_of.push_back(b.add_rowtab(rows, nrows, g.a.ld));
         }
         int tab2 = 0;
         {
-          int rows[16];
-          for (int r = 0; r < 16; ++r) rows[r] = r < P_out ? ((r / g.Wout) / g.up2) * w2 + ((r % g.Wout) / g.up2) : -1;
-          if (g.has2) tab2 = b.add_rowtab(rows);
-          for (int r = 0; r < 16; ++r) set_sbyte(proto.res_row, r, rows[r] < 0 ? 0 : rows[r]);
+          int rows[64];
+          for (int r = 0; r < nrows; ++r) rows[r] = r < P_out ? ((r / g.Wout) / g.up2) * w2 + ((r % g.Wout) / g.up2) : -1;
+          if (g.has2) tab2 = b.add_rowtab(rows, nrows, g.a2.ld);
+          for (int r = 0; r < 16; ++r) set_sbyte(proto.res_row, r, rows[r] < 0 ? 0 : (rows[r] & 0x7f));
         }
         if (b.rowtab.size() / 16 > 0x7fff) return "pixel kernel: too many row tables";
-        // passes and their step tables
+        // passes: up to 8 units = column groups x row groups of 16 (64-row outputs: the row groups of a column group share its weight stream),
+        // the rest of the 8 waves split K
         const int kchunk = fo.small ? 1 : 2;               // LDS chunks per K step
+        const int nrg = P_out > 16 ? 4 : 1;
         item_first = b.items.size();
         for (int g0 = 0; g0 < fo.groups;) {
           int grp = 1; while (grp * 2 <= PNW && grp * 2 <= fo.groups - g0) grp *= 2;
-          const int ksplit = PNW / grp;
+          int rgs = 1; while (rgs * 2 <= nrg && grp * rgs * 2 <= PNW) rgs *= 2;
+          const int ksplit = PNW / (grp * rgs);
           const int nk = (fo.F + ksplit - 1) / ksplit, nkp = (nk + PD - 1) / PD * PD;
-          PixItem it = proto;
-          it.step_base = (int)b.steps.size(); it.nkp = nkp; it.grp0 = g0; it.grp_stride = fo.F * 1024;
-          int sh = 0; while ((1 << sh) < grp) ++sh; it.gshift = sh;
-          sh = 0; while ((1 << sh) < ksplit) ++sh; it.kshift = sh;
-          for (int sl = 0; sl < ksplit; ++sl)
-            for (int j = 0; j < nkp; ++j) {
-              const int f = sl + j * ksplit;
-              PixStep e;
-              if (f < fo.F) {
-                const bool s2 = f >= (int)fo.taps.size() * fo.ndc;
-                const int ti = s2 ? 0 : f / fo.ndc, dc = s2 ? f - (int)fo.taps.size() * fo.ndc : f % fo.ndc;
-                const long long aoff = (s2 ? a2_lds : a_lds) + (long long)dc * kchunk * PCS;
-                if (b.preset && aoff > 0xffff) return "pixel kernel: LDS offset out of the step table's range";      // (the first pass lays the slabs out without reuse)
-                e.w_off = (unsigned)(fo.off + ((long long)g0 * fo.F + f) * 1024);
-                e.a_sel = (unsigned)(aoff & 0xffff) | ((unsigned)(s2 ? tab2 : tab_of[ti]) << 16) | (s2 ? 0x80000000u : 0u);
-              } else {
-                e.w_off = (unsigned)(fo.off + (long long)g0 * fo.F * 1024);
-                e.a_sel = (unsigned)(a_lds & 0xffff);       // row table 0: every row reads zeros
+          for (int rg0 = 0; rg0 < nrg; rg0 += rgs) {
+            PixItem it = proto;
+            it.step_base = (int)b.steps.size(); it.nkp = nkp; it.grp0 = g0; it.grp_stride = fo.F * 1024; it.rg0 = rg0;
+            int sh = 0; while ((1 << sh) < grp) ++sh; it.gshift = sh;
+            sh = 0; while ((1 << sh) < rgs) ++sh; it.rshift = sh;
+            sh = 0; while ((1 << sh) < ksplit) ++sh; it.kshift = sh;
+            for (int sl = 0; sl < ksplit; ++sl)
+              for (int j = 0; j < nkp; ++j) {
+                const int f = sl + j * ksplit;
+                PixStep e;
+                if (f < fo.F) {
+                  const bool s2 = f >= (int)fo.taps.size() * fo.ndc;
+                  const int ti = s2 ? 0 : f / fo.ndc, dc = s2 ? f - (int)fo.taps.size() * fo.ndc : f % fo.ndc;
+                  const long long aoff = (s2 ? a2_lds : a_lds) + (long long)dc * kchunk * PCS;
+                  if (b.preset && aoff > 0xffff) return "pixel kernel: LDS offset out of the step table's range";      // (the first pass lays the slabs out without reuse)
+                  e.w_off = (unsigned)(fo.off + ((long long)g0 * fo.F + f) * 1024);
+                  e.a_sel = (unsigned)(aoff & 0xffff) | ((unsigned)(s2 ? tab2 : tab_of[ti]) << 16) | (s2 ? 0x80000000u : 0u);
+                } else {
+                  e.w_off = (unsigned)(fo.off + (long long)g0 * fo.F * 1024);
+                  e.a_sel = (unsigned)(a_lds & 0xffff);       // row table 0: every row reads zeros
+                }
+                b.steps.push_back(e);
               }
-              b.steps.push_back(e);
-            }
-          b.items.push_back(it);
+            b.items.push_back(it);
+          }
           g0 += grp;
         }
         d.nitems = (int)b.items.size() - (int)item_first;
@@ -897,14 +972,14 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
     std::vector<size_t> placed;
     for (size_t oi : order) {
       PSlot& sl = packed[oi];
-      const int size = PBuilder::chunks_of(sl.ld);
+      const int size = PBuilder::slab_chunks(sl);
       int off = 0;
       bool moved = true;
       while (moved) {
         moved = false;
         for (size_t pj : placed) {
           const PSlot& o = packed[pj];
-          const int osize = PBuilder::chunks_of(o.ld), ooff = o.lds / PCS;
+          const int osize = PBuilder::slab_chunks(o), ooff = o.lds / PCS;
           const bool live = !(o.t1 < sl.t0 || sl.t1 < o.t0);
           if (live && off < ooff + osize && ooff < off + size) { off = ooff + osize; moved = true; }
         }
@@ -936,7 +1011,7 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
   if (!up(reinterpret_cast<void**>(&p.d_ops), b.ops.data(), sizeof(PixOpD) * b.ops.size()) ||
       !up(reinterpret_cast<void**>(&p.d_items), b.items.data(), sizeof(PixItem) * b.items.size()) ||
       !up(reinterpret_cast<void**>(&p.d_steps), b.steps.data(), sizeof(PixStep) * b.steps.size()) ||
-      !up(reinterpret_cast<void**>(&p.d_rowtab), b.rowtab.data(), b.rowtab.size())) {
+      !up(reinterpret_cast<void**>(&p.d_rowtab), b.rowtab.data(), b.rowtab.size() * sizeof(unsigned short))) {
     (void)hipFree(p.d_ops); (void)hipFree(p.d_items); (void)hipFree(p.d_steps); (void)hipFree(p.d_rowtab);
     return "pixel kernel: device allocation of a program failed";
   }

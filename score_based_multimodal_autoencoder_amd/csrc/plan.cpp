@@ -606,6 +606,9 @@ View emit_attention(Builder& b, const std::string& pre, const View& x, int c, in
     b.plan->flops_dense += dense_ref - 2.0 * b.B * (double)c * c; b.plan->flops_dense_gemm += 2.0 * b.B * ((double)c * 3 * hid + (double)hid * c) - 2.0 * b.B * (double)c * c;
     return out;
   }
+  // pixel mode: the sample-owned kernel's attention core takes at most 16 positions; above that to_qkv + core stay the fused per-layer kernel
+  const int attn_saved_chain_pix = b.chain_pix;
+  if (b.pix_mode && P > 16) b.chain_pix = 0;
   Builder::ConvSpec q;
   q.name = pre + "fn.fn.to_qkv"; q.a = x; q.cm = ChanMap::identity(c); q.cin_true = c;
   q.w = b.T(pre + "fn.fn.to_qkv.weight", (int64_t)3 * hid * c); q.cout = 3 * hid; q.Hout = H; q.Wout = W;
@@ -621,6 +624,7 @@ View emit_attention(Builder& b, const std::string& pre, const View& x, int c, in
     b.plan->flops_exec += 2.0 * b.B * 4 * (linear ? 2.0 * 32 * 32 * P : 2.0 * 32 * (double)P * P);
   }
   b.free_act(rq.out);
+  b.chain_pix = attn_saved_chain_pix;
   View out;
   if (linear) {
     Builder::ConvSpec o;
@@ -677,11 +681,12 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
   try {
     std::vector<TensorSpec> specs = unet_tensor_specs(cfg);
     Builder b(plan, B, specs, tensors);
-    // Low-resolution levels (SBM_CHAIN_PIX pixels and fewer, default 16).  Pixel mode (default, api.hip tries it first): they are marked
-    // for the sample-owned kernel at EVERY batch size, the one-position level included, and the time path stays per-layer.  Legacy
-    // mode: XCD-resident chain kernel for B >= SBM_CHAIN_MIN_B plus the row kernel for the one-position level.
+    // Levels of SBM_CHAIN_PIX pixels and fewer.  Pixel mode (default, api.hip tries it first; default 64 = the 8x8 level and below): they
+    // are marked for the sample-owned kernel at EVERY batch size, the one-position level included; the time path, the 8x8 attention core
+    // with its to_qkv (a fused kernel of their own) and init_conv's row-packed form stay per-layer.  Legacy mode (default 16): XCD-resident
+    // chain kernel for B >= SBM_CHAIN_MIN_B plus the row kernel for the one-position level.
     b.pix_mode = plan_pix_mode() == 1;
-    if (b.pix_mode) { const char* e = std::getenv("SBM_CHAIN_PIX"); const int v = e ? std::atoi(e) : 16; b.chain_pix = v < 0 ? 0 : (v > 16 ? 16 : v); b.row_pix = 0; }
+    if (b.pix_mode) { const char* e = std::getenv("SBM_CHAIN_PIX"); const int v = e ? std::atoi(e) : 64; b.chain_pix = v < 0 ? 0 : (v > 64 ? 64 : v); b.row_pix = 0; }
     else { b.chain_pix = chain_pix_from_env(B); b.row_pix = b.chain_pix > 0 ? row_pix_from_env() : 0; }
     const int level_chain_pix = b.chain_pix;
     if (b.pix_mode) b.chain_pix = 0;                                 // while the time path is emitted

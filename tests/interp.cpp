@@ -8,6 +8,7 @@
 // references it.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -332,7 +333,9 @@ const char* sbmref_error() { return g_err.c_str(); }
 void* sbmref_build(int kind, const int* cfg, int B, int z_ld, const float* const* tensors) {
   RefHandle* h = new RefHandle();
   bool ok = false;
-  if (kind == 0) ok = build_unet_plan(unet_cfg_from_ints(cfg), B, tensors, &h->plan);
+  // SBMREF_PIX=1: the plan as the product builds it for the sample-owned pixel kernel (marking, statistics layouts, pinned buffers), so
+  // that the op-by-op comparison runs against the same descriptors
+  if (kind == 0) { plan_set_pix_mode(std::getenv("SBMREF_PIX") ? 1 : 0); ok = build_unet_plan(unet_cfg_from_ints(cfg), B, tensors, &h->plan); plan_set_pix_mode(0); }
   else if (kind == 1) ok = build_resdec_plan(resdec_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);
   else if (kind == 2) { AttrDecCfg a; a.size_z = cfg[0]; a.att_size = cfg[1]; ok = build_attrdec_plan(a, B, z_ld, tensors, &h->plan); }
   else if (kind == 3) ok = build_unet_oa_plan(unet_oa_cfg_from_ints(cfg), B, z_ld, tensors, &h->plan);

@@ -242,3 +242,32 @@ def test_bench_launches_its_own_ranks_when_no_launcher_is_present():
     # with a launcher's environment the script must NOT spawn again: one process, world size from the environment
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry"], env=env, capture_output=True, text=True, timeout=300)
     assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_pixel_kernel_register_audit(tmp_path):
+    """csrc/pixrun.hip keeps its weight ring and epilogue operands in AGPRs with HARD-CODED indices (a40 .. a127), written and read by
+    inline asm.  hipcc knows nothing about values that live there between two asm statements: once the kernel needs more than its 128
+    VGPRs it spills into AGPRs -- lowest free index first -- and a spill into the ring is silent corruption (it happened during round 3:
+    wrong first K steps behind every depth-wise op, no fault).  The kernel is therefore audited at build level: outside the asm blocks no
+    instruction may name a40 or above, nothing may go to scratch, and the register total must fit two waves per SIMD."""
+    import re
+    src = os.path.join(ROOT, "score_based_multimodal_autoencoder_amd", "csrc", "pixrun.hip")
+    out = tmp_path / "pixrun.s"
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = out.read_text()
+    kern = text[text.index("pixrun_kernel"):]
+    in_asm, bad = False, []
+    for ln in kern.splitlines():
+        if ";;#ASMSTART" in ln: in_asm = True; continue
+        if ";;#ASMEND" in ln: in_asm = False; continue
+        if in_asm or ln.lstrip().startswith((";", ".")): continue
+        for m in re.finditer(r"\ba\[?(\d+)", ln):
+            if int(m.group(1)) >= 40: bad.append(ln.strip())
+    assert not bad, "compiler-generated instructions touch the reserved AGPRs a40..a127:\n" + "\n".join(bad[:10])
+    meta = text[text.index("amdhsa.kernels:"):]            # one kernel in this translation unit
+    agpr = int(re.search(r"\.agpr_count:\s+(\d+)", meta).group(1)); total = int(re.search(r"\.vgpr_count:\s+(\d+)", meta).group(1))
+    scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta).group(1))
+    assert agpr == 128 and total <= 256 and scratch == 0, (agpr, total, scratch)
+    # the hand-written part is where it should be: 16 ring loads of four dwordx4 each + the epilogue operand reads
+    assert len(re.findall(r"v_accvgpr_read_b32 v\d+, a1(0[4-9]|1\d|2[0-7])\b", kern)) == 24
