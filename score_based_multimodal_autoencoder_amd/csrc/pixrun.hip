@@ -484,7 +484,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       continue;
     }
     // ---------------------------------------------------------------- GEMM: everything comes from the item table
-#define PSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && ci < 60) dbg[128 + ci * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && ci < 96) dbg[128 + ci * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
     const int g_nitems = ldc(&op.nitems);
     for (int it = 0; it < g_nitems; ++it) {
       const int ni = ci + 1 < nitems ? ci + 1 : 0;

@@ -45,10 +45,9 @@ for first, last in runs:
         if kind == 0:
             if os.environ.get("PIX_PHASES"):
                 for p in range(passes):
-                    ph = [full[128 + (item + p) * 8 + q] for q in range(8)] if item + p < 46 else [0] * 8
-                    if all(ph[:4]):
+                    ph = [full[128 + (item + p) * 4 + q] for q in range(4)] if item + p < 96 else [0] * 4
+                    if all(ph):
                         extra += "   | pre %.2f kloop %.2f  partials+sync %.2f  epilogue+sync %.2f" % ((ph[0] - v[i]) / CLK if p == 0 else 0.0, (ph[1] - ph[0]) / CLK, (ph[2] - ph[1]) / CLK, (ph[3] - ph[2]) / CLK)
-                        if all(ph[4:]): extra += " (eread %.2f request %.2f quads %.2f stats %.2f barrier %.2f)" % ((ph[4] - ph[2]) / CLK, (ph[5] - ph[4]) / CLK, (ph[6] - ph[5]) / CLK, (ph[7] - ph[6]) / CLK, (ph[3] - ph[7]) / CLK)
             item += passes
         us = (v[i + 1] - v[i]) / CLK
         tot[KN.get(kind, kind)] = tot.get(KN.get(kind, kind), 0.0) + us
