@@ -437,13 +437,26 @@ int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_de
 int sbm_debug_gemm_stamps(sbm_model* m, const float* in_dev, float* out_dev, int i, unsigned long long* stamps_host) {
   if (!m || i < 0 || i >= (int)m->plan.ops.size() || m->plan.ops[i].kind != OP_GEMM) return fail("sbm_debug_gemm_stamps: not a GEMM op");
   unsigned long long* d = nullptr;
-  HIPCHK(hipMalloc(&d, 128)); HIPCHK(hipMemset(d, 0, 128));
+  const char* tl = getenv("SBM_GEMM_TIMELINE");          // diagnostics: file that receives every workgroup's (start, end, where) triple
+  const size_t bytes = 128 + (tl ? 6 * 8 * 65536 : 0);
+  HIPCHK(hipMalloc(&d, bytes)); HIPCHK(hipMemset(d, 0, bytes));
+  if (tl) { const unsigned long long one = 1; HIPCHK(hipMemcpy(d + 15, &one, 8, hipMemcpyHostToDevice)); }
   g_gemm_dbg = d;
   const char* e = launch_op(m->dp, i, in_dev, out_dev, m->own);
   g_gemm_dbg = nullptr;
   if (e) return fail(e);
   HIPCHK(hipStreamSynchronize(m->own));
   HIPCHK(hipMemcpy(stamps_host, d, 128, hipMemcpyDeviceToHost));
+  if (tl) {
+    std::vector<unsigned long long> h(16 + 6 * 65536);
+    HIPCHK(hipMemcpy(h.data(), d, bytes, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(tl, "a")) {
+      const int grid = (int)h[7] < 65536 ? (int)h[7] : 65536;
+      fprintf(f, "op %d grid %d\n", i, grid);
+      for (int b = 0; b < grid; ++b) fprintf(f, "%d %llu %llu %llx %llu %llu %llu %llu\n", b, h[16 + 6 * b], h[17 + 6 * b], h[18 + 6 * b], h[19 + 6 * b], h[20 + 6 * b], h[21 + 6 * b] >> 32, h[21 + 6 * b] & 0xffffffffull);
+      fclose(f);
+    }
+  }
   (void)hipFree(d);
   return 0;
 }

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave_m = wave >> 1, wave_n = wave & 1;
   unsigned long long st_t0 = 0, st_t1 = 0, st_t2 = 0, st_wait = 0, st_comp = 0, st_a = 0, st_b = 0;
-  if (g.dbg) st_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st_r0 = 0;
+  if (g.dbg) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   int bid = blockIdx.x;
   int ks = 0;
   if (g.split > 1) { ks = bid % g.split; bid /= g.split; }     // the splits of a tile are neighbours in launch order
@@ -507,9 +508,15 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
       c.stat_out[((long long)p * g.ntiles + nt) * g.B + m0 + tid] = make_float2(s, q);
     }
   }
+  if (g.dbg && tid == 0 && g.dbg[15]) {        // timeline mode (SBM_GEMM_TIMELINE): every workgroup's span on the 100 MHz clock and where it ran
+    unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* e = g.dbg + 16 + 6 * blockIdx.x;
+    e[0] = st_r0; e[1] = __builtin_amdgcn_s_memrealtime(); e[2] = ((unsigned long long)xcc << 32) | hw; e[3] = (st_wait & 0xffffffffull) | ((__builtin_amdgcn_s_memtime() - st_t0) << 32); e[4] = st_comp; e[5] = ((unsigned long long)(c1 - c0) << 32) | (unsigned)(st_t2 - st_t1 > 0xffffffffull ? 0xffffffffull : st_t2 - st_t1);
+  }
   if (g.dbg && tid == 0 && (int)blockIdx.x == (int)(gridDim.x / 2)) {
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-    g.dbg[0] = st_t1 - st_t0; g.dbg[1] = st_t2 - st_t1; g.dbg[2] = t3 - st_t2; g.dbg[3] = st_wait; g.dbg[4] = 0; g.dbg[5] = st_comp;
+    g.dbg[0] = st_t1 - st_t0; g.dbg[1] = st_t2 - st_t1; g.dbg[2] = t3 - st_t2; g.dbg[3] = st_wait; g.dbg[4] = __builtin_amdgcn_s_memrealtime() - st_r0; g.dbg[5] = st_comp;      // [4]: the same span as [0]+[1]+[2] on the 100 MHz clock
     g.dbg[8] = st_p1 - st_t1; g.dbg[9] = st_p2 - st_p1; g.dbg[10] = st_p3 - st_p2; g.dbg[11] = st_p4 - st_p3;
     g.dbg[6] = (unsigned long long)total; g.dbg[7] = gridDim.x;
   }

@@ -65,6 +65,6 @@ if os.environ.get("SBM_STAMPS"):
             continue
         _lib.check(L.sbm_debug_gemm_stamps(eng.h, x.data_ptr(), out.data_ptr(), i, st))
         v = list(st)
-        print(f"{i:3d} {buf.value.decode()[:44]:44s} pro {v[0]:7d} loop {v[1]:8d} epi {v[2]:7d} | wait {v[3]:8d} issue {v[4]:7d} comp {v[5]:8d} | "
+        print(f"{i:3d} {buf.value.decode()[:44]:44s} pro {v[0]:7d} loop {v[1]:8d} epi {v[2]:7d} | wait {v[3]:8d} clock {(v[0] + v[1] + v[2]) / max(v[4], 1) * 100:5.0f} MHz comp {v[5]:8d} | "
               f"chunks {v[6]:3d} grid {v[7]:5d}  cyc/chunk {v[5] / max(v[6], 1):6.0f} | prefill {v[8]:6d} gnload {v[9]:6d} gnred {v[10]:6d} setup {v[11]:5d}")
 print(f"total {tot:.1f} us; dense FLOP {eng.info['flops_dense'] / 1e9:.2f} G, exec FLOP {eng.info['flops_exec'] / 1e9:.2f} G")
