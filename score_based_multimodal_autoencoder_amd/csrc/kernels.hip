@@ -1237,7 +1237,7 @@ __global__ void sinus_kernel(const float* t, const float* freq, float* out, int 
 // GroupNorm(G, C) (+ SiLU), materialised (unet_openai normalization()): one workgroup per sample; every thread
 // always touches the same channel quads, hence the same groups, so the group sums reduce in a fixed order.
 // ------------------------------------------------------------------------------------------------
-struct Gn32Args { const float* in; float* out; const float* gamma; const float* beta; double2* partial; int B, P, C, ldi, ldo, groups, silu, slices, vslices; };
+struct Gn32Args { const float* in; float* out; const float* gamma; const float* beta; double2* partial; int B, P, C, ldi, ldo, groups, silu, slices, vslices, gpw; };
 
 __global__ __launch_bounds__(256) void gn32_kernel(const Gn32Args a) {
   __shared__ float2 part[256 * 2];
@@ -1379,6 +1379,72 @@ __global__ __launch_bounds__(256) void gn32_apply_kernel(const Gn32Args a) {
     }
     for (; p < a.P; p += stride)
       *reinterpret_cast<float4*>(a.out + ((long long)p * a.B + b) * a.ldo + c4 * 4) = norm(*reinterpret_cast<const float4*>(a.in + ((long long)p * a.B + b) * a.ldi + c4 * 4));
+  }
+}
+
+// Tensors of up to 16 K floats per (sample, group bundle) -- every GroupNorm(32) of configs 4/5: the 16x16 ... 2x2 levels of UNetModel --
+// in ONE launch with ONE read: a workgroup owns sample b and `gpw` neighbouring groups (>= 128 contiguous bytes per pixel, so the reads
+// are whole cache lines), keeps its elements in registers (<= 16 float4 per thread), takes the mean, then the centred sum of squares from
+// the registers (no E[x^2] - mean^2 cancellation), normalises, applies SiLU and writes.  gpw depends on the tensor shape only, the sums
+// are reduced in a fixed order: a sample's result depends neither on scheduling nor on the batch it is computed in.
+__global__ __launch_bounds__(256) void gn32_reg_kernel(const Gn32Args a) {
+  __shared__ float part[256];
+  __shared__ float2 stat[8];
+  const int tid = threadIdx.x, b = blockIdx.x, bun = blockIdx.y;
+  const int cg = a.C / a.groups, cq = cg >> 2, W4 = a.gpw * cq, R = 256 / W4;
+  const int q = tid % W4, r = tid / W4;
+  const bool active = r < R;
+  const int c0 = bun * a.gpw * cg + q * 4, gl = q / cq;
+  const int E = cq * R;                                     // partial sums per group
+  float4 v[16];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = r + i * R;
+    v[i] = (active && p < a.P) ? *reinterpret_cast<const float4*>(a.in + ((long long)p * a.B + b) * a.ldi + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const double inv_n = 1.0 / ((double)a.P * cg);
+  auto group_sum = [&](float mine) -> double {            // sum of the `E` partials of group (tid >> 4), valid in lanes with (tid & 15) == 0
+    part[tid] = active ? mine : 0.f;
+    __syncthreads();
+    double acc = 0.0;
+    const int g = tid >> 4, l = tid & 15;
+    if (g < a.gpw)
+      for (int e = l; e < E; e += 16) acc += (double)part[(e / cq) * W4 + g * cq + e % cq];
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) acc += __shfl_xor(acc, m);
+    return acc;
+  };
+  double t = group_sum(s);
+  if ((tid & 15) == 0 && (tid >> 4) < a.gpw) stat[tid >> 4].x = (float)(t * inv_n);
+  __syncthreads();
+  const float mean = stat[gl].x;
+  float qq = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (active && r + i * R < a.P) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      qq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  }
+  __syncthreads();                                          // everyone has read its partial sums' successor slot
+  t = group_sum(qq);
+  if ((tid & 15) == 0 && (tid >> 4) < a.gpw) stat[tid >> 4].y = (float)(1.0 / sqrt(t * inv_n + 1e-5));
+  __syncthreads();
+  if (!active) return;
+  const float rstd = stat[gl].y;
+  const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c0), be = *reinterpret_cast<const float4*>(a.beta + c0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int p = r + i * R;
+    if (p < a.P) {
+      float4 y;
+      y.x = ((v[i].x - mean) * rstd) * ga.x + be.x; y.y = ((v[i].y - mean) * rstd) * ga.y + be.y;
+      y.z = ((v[i].z - mean) * rstd) * ga.z + be.z; y.w = ((v[i].w - mean) * rstd) * ga.w + be.w;
+      if (a.silu) { y.x = act_apply(ACT_SILU, y.x); y.y = act_apply(ACT_SILU, y.y); y.z = act_apply(ACT_SILU, y.z); y.w = act_apply(ACT_SILU, y.w); }
+      *reinterpret_cast<float4*>(a.out + ((long long)p * a.B + b) * a.ldo + c0) = y;
+    }
   }
 }
 
@@ -1717,7 +1783,17 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
         const int c4n = a.C / 4, rpi = c4n >= 256 ? 1 : 256 / c4n, sweeps = ceil_div(a.P, rpi);
         a.vslices = sweeps < 16 ? sweeps : 16;                  // a function of the tensor shape only
       }
+      // register-resident single pass (gn32_reg_kernel): a bundle of gpw groups = the fewest whole groups that cover a 128-byte line
+      a.gpw = 0;
+      if (o.in.C % (4 * o.groups) == 0) {
+        static const bool reg_on = [] { const char* e = getenv("SBM_GN32_REG"); return !e || atoi(e) != 0; }();
+        const int cg = a.C / o.groups;
+        int gpw = 1; while (gpw * cg < 32 && gpw < 8 && o.groups % (gpw * 2) == 0) gpw *= 2;
+        const int W4 = gpw * cg / 4, R = W4 <= 256 ? 256 / W4 : 0;
+        if (reg_on && R > 0 && ceil_div(a.P, R) <= 16 && o.groups % gpw == 0) a.gpw = gpw;
+      }
       if (o.in.C % (4 * o.groups)) SBM_KLAUNCH(gn32_small_kernel, dim3(ceil_div(o.B * o.groups, 256)), dim3(256), 0, st, a);
+      else if (a.gpw) SBM_KLAUNCH(gn32_reg_kernel, dim3(o.B, o.groups / a.gpw), dim3(256), 0, st, a);
       else if (two_pass) {
         if (g_prof_start) {      // profiling: one event pair spans both launches
           hipExtLaunchKernelGGL(gn32_stats_kernel, dim3(o.B, a.vslices), dim3(256), 0, st, g_prof_start, nullptr, 0, a);
