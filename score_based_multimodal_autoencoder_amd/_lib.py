@@ -22,7 +22,7 @@ OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "n
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy", "sbm_model_check",
            "sbm_model_info", "sbm_model_note", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step", "sbm_langevin_norms", "sbm_langevin_update", "sbm_clg_forward", "sbm_clg_guide",
-           "sbm_fill_normal", "sbm_sampler_run", "sbm_cond_sampler_run", "sbm_langevin_fixed_step", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
+           "sbm_fill_normal", "sbm_sampler_run", "sbm_cond_sampler_run", "sbm_langevin_fixed_step", "sbm_langevin_run", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_ctl", "sbm_debug_chain_stamps", "sbm_debug_row_stamps", "sbm_debug_pix_stamps",
            "sbm_ddpm_step", "sbm_fid_accumulate", "sbm_fid_finalize_stats", "sbm_fid_work_doubles", "sbm_fid_frechet", "sbm_debug_dgemm_tn"]
 
@@ -103,6 +103,7 @@ def lib():
         L.sbm_model_gemm_flops.argtypes = [vp, ctypes.POINTER(dbl)]
         L.sbm_em_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
         L.sbm_langevin_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
+        L.sbm_langevin_run.argtypes = [vp, vp, vp, ctypes.c_uint, i, i, vp, vp, u64, u64, i, ctypes.POINTER(ctypes.c_float), vp]
         L.sbm_langevin_norms.argtypes = [vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
         L.sbm_langevin_update.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_long, i, i, u64, u64, i, i, vp]
         L.sbm_clg_forward.argtypes = [vp, vp, vp, i, i, vp, i, vp]

@@ -826,6 +826,40 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
   return nullptr;
 }
 
+struct TableModeGuard {        // whatever happens in a loop, later forwards read their own time inputs again
+  sbm_model* m; hipStream_t st; bool armed = false;
+  ~TableModeGuard() { if (armed) { (void)hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st); (void)hipStreamSynchronize(st); } }
+};
+struct GraphGuard {            // every exit path (HIPCHK returns included) releases the captured step; the stream is drained first
+  hipStream_t st; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+  ~GraphGuard() { if (exec || graph) (void)hipStreamSynchronize(st); if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
+};
+
+// Every sample of a sampling loop shares the iteration's time input: tabulate the time path (sinusoid, time MLP, per-block condition
+// GEMM) for all N iterations once, B at a time through the very same ops (hence bit-identical to the per-forward path); the depthwise
+// kernels then index the table by the device step counter and the per-iteration launches of the time path disappear.  Leaves the
+// model in table mode (the caller's guard switches it back).
+static int build_time_table(sbm_model* m, const float* times_dev, int N, const float* x_any, hipStream_t st, const char* who) {
+  const int B = m->plan.B, ld = m->plan.cond_ld;
+  const size_t need = (size_t)N * ld;
+  if (need > m->time_table_floats) {
+    if (m->d_time_table) (void)hipFree(m->d_time_table);
+    m->d_time_table = nullptr; m->time_table_floats = 0;
+    HIPCHK(hipMalloc(&m->d_time_table, need * sizeof(float)));
+    m->time_table_floats = need;
+  }
+  for (int k0 = 0; k0 < N; k0 += B) {
+    const int n = N - k0 < B ? N - k0 : B;
+    HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, times_dev + k0, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
+    if (const char* e = run_plan(m->dp, x_any, m->d_ws + m->plan.time_off, m->d_score, st, 2)) return fail(std::string(who) + ": " + e);
+    HIPCHK(hipMemcpyAsync(m->d_time_table + (size_t)k0 * ld, m->d_ws + m->plan.cond_off, sizeof(float) * (size_t)n * ld, hipMemcpyDeviceToDevice, st));
+  }
+  StepCtl h{}; h.step = 0; h.table_mode = 1; h.tab_ld = ld; h.pad = 0; h.table = m->d_time_table;
+  HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(m->d_counter) + 4, reinterpret_cast<const char*>(&h) + 4, sizeof(StepCtl) - 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipStreamSynchronize(st));                            // `h` is a stack object
+  return 0;
+}
+
 static int sampler_run_impl(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const sbm_cond_cfg* cond, const float* z_obs,
                             const float* timesteps, const float* alphas, const float* noise, float* x_inout, float* x_mean_out, int first_step,
                             int n_run, float* elapsed_ms, void* stream) {
@@ -849,14 +883,8 @@ static int sampler_run_impl(sbm_model* m, const sbm_sde_cfg* sde, const sbm_samp
   HIPCHK(hipEventRecord(m->ev_in, caller));
   HIPCHK(hipStreamWaitEvent(st, m->ev_in, 0));
   launch_set_counter(m->d_counter, first_step, st);
-  struct TableModeGuard {      // whatever happens below, later forwards read their own time inputs again
-    sbm_model* m; hipStream_t st; bool armed = false;
-    ~TableModeGuard() { if (armed) { (void)hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st); (void)hipStreamSynchronize(st); } }
-  } guard{m, st};
-  struct GraphGuard {          // every exit path (HIPCHK returns included) releases the captured step; the stream is drained first
-    hipStream_t st; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
-    ~GraphGuard() { if (exec || graph) (void)hipStreamSynchronize(st); if (exec) (void)hipGraphExecDestroy(exec); if (graph) (void)hipGraphDestroy(graph); }
-  } gg{st};
+  TableModeGuard guard{m, st};
+  GraphGuard gg{st};
   hipGraph_t& graph = gg.graph; hipGraphExec_t& exec = gg.exec;
   const char* e = nullptr;
   // Every sample of the loop shares the step's time: tabulate the time path (sinusoid, time MLP, per-block condition GEMM)
@@ -864,23 +892,7 @@ static int sampler_run_impl(sbm_model* m, const sbm_sde_cfg* sde, const sbm_samp
   // step counter and the per-step launches of the time path disappear.
   const bool time_table = m->plan.cond_off >= 0 && m->plan.time_off >= 0 && !std::getenv("SBM_NO_TIME_TABLE");
   if (time_table) {
-    const int N = sde->N, B = m->plan.B, ld = m->plan.cond_ld;
-    const size_t need = (size_t)N * ld;
-    if (need > m->time_table_floats) {
-      if (m->d_time_table) (void)hipFree(m->d_time_table);
-      m->d_time_table = nullptr; m->time_table_floats = 0;
-      HIPCHK(hipMalloc(&m->d_time_table, need * sizeof(float)));
-      m->time_table_floats = need;
-    }
-    for (int k0 = 0; k0 < N; k0 += B) {
-      const int n = N - k0 < B ? N - k0 : B;
-      HIPCHK(hipMemcpyAsync(m->d_ws + m->plan.time_off, timesteps + k0, sizeof(float) * n, hipMemcpyDeviceToDevice, st));
-      if ((e = run_plan(m->dp, x_inout, m->d_ws + m->plan.time_off, m->d_score, st, 2))) return fail(std::string("sbm_sampler_run: ") + e);
-      HIPCHK(hipMemcpyAsync(m->d_time_table + (size_t)k0 * ld, m->d_ws + m->plan.cond_off, sizeof(float) * (size_t)n * ld, hipMemcpyDeviceToDevice, st));
-    }
-    StepCtl h{}; h.step = 0; h.table_mode = 1; h.tab_ld = ld; h.pad = 0; h.table = m->d_time_table;
-    HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(m->d_counter) + 4, reinterpret_cast<const char*>(&h) + 4, sizeof(StepCtl) - 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipStreamSynchronize(st));                            // `h` is a stack object
+    if (int rc = build_time_table(m, timesteps, sde->N, x_inout, st, "sbm_sampler_run")) return rc;
     guard.armed = true;
   }
   if (cfg->use_graph && n_run > 1) {
@@ -929,6 +941,70 @@ int sbm_cond_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler
                          int n_run, float* elapsed_ms, void* stream) {
   if (!cond) return fail("sbm_cond_sampler_run: bad arguments");
   return sampler_run_impl(m, sde, cfg, cond, z_obs, timesteps, alphas, noise, x_inout, x_mean_out, first_step, n_run, elapsed_ms, stream);
+}
+
+// Device-resident annealed-Langevin loop (fid_upd10.gen_ae :84-99, eval_lat_celeba_hq_all.evaluate :258-275): n_iter iterations of
+//   score = net(z, times[k]);  z[:, m] += a[k][m] * score[:, m] / score_div[k] + b[k][m] * N   (m in mod_mask)
+// with the iteration index in device memory, the time path tabulated once for all iterations, and ONE captured graph
+// {score net, update, advance} replayed n_iter times.  coef rows: [a_0..a_{n_mod-1} | b_0..b_{n_mod-1} | score_div].
+int sbm_langevin_run(sbm_model* m, const float* times, const float* coef, unsigned mod_mask, int n_mod, int n_iter, const float* noise, float* z_inout,
+                     uint64_t seed, uint64_t sample_offset, int use_graph, float* elapsed_ms, void* stream) {
+  if (!m || (m->kind != SBM_UNET && m->kind != SBM_UNET_OA) || !times || !coef || !z_inout || n_iter < 0 || n_mod <= 0 || n_mod > 32) return fail("sbm_langevin_run: bad arguments");
+  const int B = m->plan.B, CHW = m->plan.out_C * m->plan.out_H * m->plan.out_W;
+  if (m->plan.in_C != m->plan.out_C) return fail("sbm_langevin_run: score net must map the state onto itself");
+  if (CHW % n_mod || (CHW / n_mod) % 4) return fail("sbm_langevin_run: the state must split into n_mod modalities of a multiple of 4 floats");
+  if (!m->plan.needs_time || m->plan.cond_off < 0 || m->plan.time_off < 0) return fail("sbm_langevin_run: the score net has no tabulated time path");
+  if (m->plan.aux_off >= 0 && !m->aux_persistent) return fail("sbm_langevin_run: the score net was built with z conditioning; call sbm_model_set_aux first");
+  m->dp.aux = m->aux_persistent;
+  hipStream_t caller = (hipStream_t)stream, st = m->own;
+  if (int rc = chain_prior_abort(m, st, "sbm_langevin_run")) return rc;
+  HIPCHK(hipEventRecord(m->ev_in, caller));
+  HIPCHK(hipStreamWaitEvent(st, m->ev_in, 0));
+  launch_set_counter(m->d_counter, 0, st);
+  TableModeGuard guard{m, st};
+  GraphGuard gg{st};
+  if (n_iter > 0) {
+    if (int rc = build_time_table(m, times, n_iter, z_inout, st, "sbm_langevin_run")) return rc;
+    guard.armed = true;
+  }
+  StepArgs a{};
+  a.x = z_inout; a.x_out = z_inout; a.score = m->d_score; a.noise = noise; a.noise_step_stride = (long long)B * CHW; a.step_counter = m->d_counter;
+  a.B = B; a.CHW = CHW; a.seed = seed; a.sample_offset = sample_offset; a.draw = 0;
+  auto enqueue = [&]() -> const char* {
+    if (const char* e = run_plan(m->dp, z_inout, m->d_ws + m->plan.time_off, m->d_score, st, 1)) return e;
+    launch_axpy_noise_tab(a, coef, mod_mask, n_mod, CHW / n_mod, st);              // element-wise: in place is safe
+    launch_advance(m->d_counter, st);
+    return nullptr;
+  };
+  if (use_graph && n_iter > 1) {
+    HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const char* e = enqueue();
+    hipError_t ce = hipStreamEndCapture(st, &gg.graph);
+    if (e) return fail(std::string("sbm_langevin_run: ") + e);
+    if (ce != hipSuccess) return fail_hip("hipStreamEndCapture", ce);
+    HIPCHK(hipGraphInstantiate(&gg.exec, gg.graph, nullptr, nullptr, 0));
+  }
+  if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t0, st));
+  for (int i = 0; i < n_iter; ++i) {
+    if (gg.exec) { hipError_t le = hipGraphLaunch(gg.exec, st); if (le != hipSuccess) return fail_hip("hipGraphLaunch", le); }
+    else if (const char* e = enqueue()) return fail(std::string("sbm_langevin_run: ") + e);
+  }
+  if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t1, st));
+  if (guard.armed) { HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st)); guard.armed = false; }
+  HIPCHK(hipEventRecord(m->ev_out, st));
+  HIPCHK(hipStreamWaitEvent(caller, m->ev_out, 0));
+  if (elapsed_ms || gg.exec) {
+    hipError_t se = hipStreamSynchronize(st);
+    if (se != hipSuccess) return fail_hip("hipStreamSynchronize", se);
+    if (elapsed_ms) HIPCHK(hipEventElapsedTime(elapsed_ms, m->ev_t0, m->ev_t1));
+    if (m->h_abort && __atomic_load_n(m->h_abort, __ATOMIC_RELAXED)) {
+      (void)hipMemset(m->d_chain_sync, 0, sizeof(ChainSync));
+      __atomic_store_n(m->h_abort, 0u, __ATOMIC_RELAXED);
+      return fail("sbm_langevin_run: a chain-kernel barrier timed out (not every workgroup was resident?); results are invalid");
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 }  // extern "C"

@@ -235,6 +235,7 @@ void ensure_dynamic_lds(const void* fn, int bytes);
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;   // armed by arm_profile_events (kernels.hip)
 void launch_set_counter(int* step_counter, int value, hipStream_t st);
 void launch_axpy_noise(const StepArgs& a, float ca, float cb, float sdiv, unsigned mod_mask, int per_mod, hipStream_t st);
+void launch_axpy_noise_tab(const StepArgs& a, const float* coef, unsigned mod_mask, int n_mod, int per_mod, hipStream_t st);
 void launch_renoise(const StepArgs& a, const float* z_obs, unsigned obs_mask, int per_mod, hipStream_t st, int plain = 0);   // plain: copy the clean observed latents
 
 }  // namespace sbm

@@ -161,6 +161,30 @@ __global__ __launch_bounds__(256) void axpy_noise_kernel(const StepArgs a, float
   }
   *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
 }
+// The same update inside a device-resident loop (sbm_langevin_run): the iteration index is the device step counter, and the iteration's
+// coefficients come from a table row [a_0 .. a_{n_mod-1} | b_0 .. b_{n_mod-1} | score_div] -- one captured launch serves every iteration.
+__global__ __launch_bounds__(256) void axpy_noise_tab_kernel(const StepArgs a, const float* __restrict__ coef, unsigned mod_mask, int n_mod, int per_mod) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int q4 = a.CHW >> 2;
+  if (idx >= (long long)a.B * q4) return;
+  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
+  const int step = *a.step_counter, mod = e / per_mod;
+  const float* row = coef + (long long)step * (2 * n_mod + 1);
+  const float4 x = *reinterpret_cast<const float4*>(a.x + (long long)b * a.CHW + e);
+  float4 o = x;
+  if ((mod_mask >> mod) & 1u) {
+    const float ca = row[mod], cb = row[n_mod + mod], sdiv = row[2 * n_mod];
+    float4 s = *reinterpret_cast<const float4*>(a.score + (long long)b * a.CHW + e);
+    s.x = s.x / sdiv; s.y = s.y / sdiv; s.z = s.z / sdiv; s.w = s.w / sdiv;
+    const float4 z = load_noise4(a, b, e, (unsigned)step);
+    o.x = (x.x + ca * s.x) + cb * z.x; o.y = (x.y + ca * s.y) + cb * z.y; o.z = (x.z + ca * s.z) + cb * z.z; o.w = (x.w + ca * s.w) + cb * z.w;
+  }
+  *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
+}
+void launch_axpy_noise_tab(const StepArgs& a, const float* coef, unsigned mod_mask, int n_mod, int per_mod, hipStream_t st) {
+  const long long n = (long long)a.B * (a.CHW >> 2);
+  hipLaunchKernelGGL(axpy_noise_tab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, coef, mod_mask, n_mod, per_mod);
+}
 void launch_axpy_noise(const StepArgs& a, float ca, float cb, float sdiv, unsigned mod_mask, int per_mod, hipStream_t st) {
   const long long n = (long long)a.B * (a.CHW >> 2);
   hipLaunchKernelGGL(axpy_noise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, ca, cb, sdiv, mod_mask, per_mod);

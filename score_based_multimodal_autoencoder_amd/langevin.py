@@ -9,6 +9,8 @@ state is the concatenated tensor itself (modalities in sorted-key order) and `pr
 that move -- the others are the observed (conditioning) latents and pass through unchanged, as in the reference.
 The update kernels are the HIP library's (`sbm_langevin_fixed_step`); there is no CPU path.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -62,8 +64,15 @@ def _per_mod(v, n_mod, predicted):
     return vals
 
 
+def _fused_score_net(score_model, hw):
+    """True when `score_model` is this package's time-conditioned `Unet` called as score_model(z.view(B, n_mod, *hw), sigma_index) --
+    the reference's own call (fid_upd10.py:91): the whole loop then runs on the device.  Any other callable takes the Python loop."""
+    from .unet_model import Unet
+    return isinstance(score_model, Unet) and score_model.with_time_emb and not score_model.training
+
+
 def annealed_langevin(score_model, z, sigmas=None, er=None, c=None, iter_num=None, predicted=None, noise=None, *, seed=None,
-                      sample_offset=0, hw=(8, 8)):
+                      sample_offset=0, hw=(8, 8), fused=None, return_timing=False):
     """Annealed Langevin over `sigmas` (fid_upd10.gen_ae :84-99; eval_lat_celeba_hq_all.evaluate :258-275).
 
     z (B, n_mod, size_z); score_model(z.view(B, n_mod, *hw), sigma_index) -> same shape.  Per level i and inner
@@ -72,6 +81,8 @@ def annealed_langevin(score_model, z, sigmas=None, er=None, c=None, iter_num=Non
     Defaults follow gen_ae: (er, c, iter_num) = (0.01, 0.7, 2) when 10 modalities are predicted, else (2e-3, 0.5, 20).
     er / c may be per-modality sequences or dicts (the CelebA evaluator's er[mod], c[mod]).
     noise: optional (len(sigmas)*iter_num, B, n_mod, size_z) injected normals (parity tests); default in-kernel Philox.
+    fused: None (default) = the device-resident loop when `score_model` is this package's `Unet`, the Python loop over the same HIP
+    kernels for any other callable; False forces the Python loop (the two agree bit for bit: tests/test_gpu_alt.py).
     """
     z = as_f32_cuda(z, "z").clone()
     B, n_mod = z.shape[0], z.shape[1]
@@ -85,8 +96,40 @@ def annealed_langevin(score_model, z, sigmas=None, er=None, c=None, iter_num=Non
         groups.setdefault((ers[m], cs[m]), []).append(m)
     sig = default_sigmas() if sigmas is None else np.asarray(torch.as_tensor(sigmas).detach().cpu().numpy(), np.float64)
     seed = fresh_seed(seed)
+    if fused is None:
+        fused = _fused_score_net(score_model, hw)
+    if fused:
+        # device-resident loop (sbm_langevin_run): iteration counter on the device, time path tabulated once, one captured graph per
+        # iteration replayed len(sigmas) * iter_num times -- the same kernels, coefficients and Philox stream as the loop below
+        n_iter = sig.size * iter_num
+        rows = np.zeros((n_iter, 2 * n_mod + 1), np.float32)
+        times = np.repeat(np.arange(sig.size, dtype=np.float32), iter_num)
+        mask = 0
+        for (er_g, c_g), mods in groups.items():
+            for i in range(sig.size):
+                alpha = er_g * (sig[i] ** 2) / (sig[-1] ** 2)
+                for m in mods:
+                    rows[i * iter_num:(i + 1) * iter_num, m] = np.float32(alpha)
+                    rows[i * iter_num:(i + 1) * iter_num, n_mod + m] = np.float32(c_g * np.sqrt(2 * alpha))
+            for m in mods:
+                mask |= 1 << m
+        rows[:, 2 * n_mod] = np.repeat(sig.astype(np.float32), iter_num)
+        eng = score_model._engine_for(B, hw[0], hw[1])
+        coef = torch.from_numpy(rows).to(z.device); tdev = torch.from_numpy(times).to(z.device)
+        if noise is not None:
+            noise = as_f32_cuda(noise, "noise")
+            if noise.shape[0] < n_iter:
+                raise ValueError(f"noise needs {n_iter} draws")
+        ms = ctypes.c_float(0.0)
+        _lib.check(_lib.lib().sbm_langevin_run(eng.h, tdev.data_ptr(), coef.data_ptr(), mask, n_mod, n_iter,
+                                               noise.data_ptr() if noise is not None else None, z.data_ptr(), seed, int(sample_offset), 1,
+                                               ctypes.byref(ms) if return_timing else None, _lib.stream_ptr()))
+        return (z, ms.value) if return_timing else z
     single = len(groups) == 1
     buf = torch.empty_like(z) if single else None
+    if return_timing:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     with torch.no_grad():
         k = 0
         for i in range(sig.size):
@@ -101,6 +144,9 @@ def annealed_langevin(score_model, z, sigmas=None, er=None, c=None, iter_num=Non
                 if single:
                     z, buf = buf, z
                 k += 1
+    if return_timing:
+        ev1.record(); ev1.synchronize()
+        return z, ev0.elapsed_time(ev1)
     return z
 
 

@@ -143,6 +143,31 @@ def test_annealed_langevin_per_modality_coefficients_and_philox(pkg):
     assert not torch.equal(a, c)
 
 
+def test_annealed_langevin_device_loop_equals_python_loop_bit_for_bit(pkg):
+    """with this package's Unet as the score model the whole chain runs on the device (sbm_langevin_run: iteration counter in
+    device memory, tabulated time path, one captured graph per iteration) -- the same kernels, coefficients and Philox stream as the
+    Python loop, so the two agree bit for bit, with in-kernel and with injected noise; the model serves ordinary forwards afterwards."""
+    lang = pkg["lang"]
+    unet = _filled(pkg, pkg["unet"].Unet(channels=3, **TINY)).eval()
+    z0 = torch.randn(4, 3, 64, device="cuda")
+    sig = np.linspace(5, 0.1, 6)
+    kw = dict(sigmas=sig, er={1: 2e-3, 2: 1e-3}, c={1: 0.5, 2: 0.2}, iter_num=3, predicted=[1, 2], seed=11)
+    t = torch.full((4,), 2.0, device="cuda")
+    before = unet(z0.view(4, 3, 8, 8), t).clone()
+    a = lang.annealed_langevin(unet, z0, fused=True, **kw)
+    b = lang.annealed_langevin(unet, z0, fused=False, **kw)
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a[:, 0], z0[:, 0]) and not torch.equal(a[:, 1], z0[:, 1])
+    assert torch.equal(lang.annealed_langevin(unet, z0, **kw), a)                     # default: the device loop for a bare Unet
+    nz = torch.randn(18, 4, 3, 64, device="cuda")
+    kw.pop("seed")
+    a2 = lang.annealed_langevin(unet, z0, noise=nz, fused=True, **kw)
+    b2 = lang.annealed_langevin(unet, z0, noise=nz, fused=False, **kw)
+    assert torch.equal(a2, b2) and not torch.equal(a2, a)
+    assert torch.equal(unet(z0.view(4, 3, 8, 8), t), before)                          # table mode is off again
+    z1, ms = lang.annealed_langevin(unet, z0, seed=11, return_timing=True, **kw)
+    assert torch.equal(z1, a) and ms > 0
+
+
 @pytest.mark.parametrize("tag,noise_obs,pc", [("nobs1_pc1", True, True), ("nobs0_pc0", False, False)])
 def test_conditional_loop_matches_evaluate(pkg, golden, tag, noise_obs, pc):
     g = golden("conditional.npz")

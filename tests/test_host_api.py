@@ -271,3 +271,34 @@ def test_pixel_kernel_register_audit(tmp_path):
     assert agpr == 128 and total <= 256 and scratch == 0, (agpr, total, scratch)
     # the hand-written part is where it should be: 16 ring loads of four dwordx4 each + the epilogue operand reads
     assert len(re.findall(r"v_accvgpr_read_b32 v\d+, a1(0[4-9]|1\d|2[0-7])\b", kern)) == 24
+
+
+def test_engine_fingerprint_sees_every_kind_of_weight_change_and_does_not_walk_the_tree_per_call():
+    """The engine cache key: the tensor list is cached (the tree walk cost as much as a forward), and still every way a
+    weight can change invalidates the engines: in-place update, `.data` swap, `load_state_dict`, a NEW nn.Parameter assigned to a
+    sub-module, a buffer re-registered."""
+    m = Unet(dim=8, channels=2, dim_mults=(1, 2)).eval()
+    fp0 = m._fingerprint()
+    lst = m.__dict__["_sbm_tensors"]
+    assert m._fingerprint() == fp0 and m.__dict__["_sbm_tensors"] is lst            # second call: same list object, no walk
+    p = next(m.parameters())
+    with torch.no_grad():
+        p.add_(1.0)
+    fp1 = m._fingerprint()
+    assert fp1 != fp0
+    p.data = p.data.clone()
+    fp2 = m._fingerprint()
+    assert fp2 != fp1
+    m.load_state_dict({k: v.clone() for k, v in m.state_dict().items()})
+    fp3 = m._fingerprint()
+    assert fp3 != fp2
+    name = next(n for n, _ in m.named_parameters())
+    owner = m
+    for part in name.split(".")[:-1]:
+        owner = getattr(owner, part)
+    setattr(owner, name.split(".")[-1], torch.nn.Parameter(torch.zeros_like(p)))
+    fp4 = m._fingerprint()
+    assert fp4 != fp3 and m.__dict__["_sbm_tensors"] is not lst                       # the list was re-collected
+    assert any(t is getattr(owner, name.split(".")[-1]) for t in m.__dict__["_sbm_tensors"])
+    m.double()
+    assert m._fingerprint() != fp4
