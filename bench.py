@@ -214,6 +214,7 @@ def extra_measurements(cfg, score, decs, sde, x0, zc, device):
     """The rest of the path's surface, timed with the sampler's own event timing or wall clock around a synchronised region (VERDICT r2
     item 6; SURVEY 8(d): "with and without the corrector").  Config 2 only carries the PolyMNIST-specific entries."""
     from score_based_multimodal_autoencoder_amd import langevin as LG
+    from score_based_multimodal_autoencoder_amd import synth
     from score_based_multimodal_autoencoder_amd.sde_helper2 import cond_sampler, uncond_sampler
     W = WORK[cfg]
     B = x0.shape[0]
@@ -241,12 +242,40 @@ def extra_measurements(cfg, score, decs, sde, x0, zc, device):
         out["cond_sampler_fused"] = {"error": str(exc)[:200]}
     if cfg == 2:
         try:
-            sig = torch.exp(torch.linspace(math.log(1.0), math.log(0.01), 10))
-            n_calls = 10 * 20
-            t, _ = wall(lambda: LG.annealed_langevin(score, x0.reshape(B, W["n_mod"], -1), sig, iter_num=20, seed=13, hw=(W["hw"], W["hw"])))
-            out["annealed_langevin"] = {"score_calls_per_s": n_calls / t, "ms_per_score_call": 1e3 * t / n_calls, "note": "fid_upd10.gen_ae shape: 10 sigma levels x 20 steps, Python loop over fused step kernels"}
+            # fid_upd10.gen_ae shape (:84-99): sigma ladder x inner iterations, the Unet called with the level index as its time input
+            sig = torch.exp(torch.linspace(math.log(1.0), math.log(0.01), 50))
+            n_calls = 50 * 4
+            z0 = x0.reshape(B, W["n_mod"], -1)
+            LG.annealed_langevin(score, z0, sig, iter_num=4, seed=13, hw=(W["hw"], W["hw"]))             # engines / graph warm
+            t_dev, _ = wall(lambda: LG.annealed_langevin(score, z0, sig, iter_num=4, seed=13, hw=(W["hw"], W["hw"])))
+            t_py, _ = wall(lambda: LG.annealed_langevin(score, z0, sig, iter_num=4, seed=13, hw=(W["hw"], W["hw"]), fused=False))
+            out["annealed_langevin"] = {"score_calls_per_s": n_calls / t_dev, "ms_per_score_call": 1e3 * t_dev / n_calls,
+                                        "python_loop_ms_per_score_call": 1e3 * t_py / n_calls,
+                                        "note": "50 sigma levels x 4 iterations; device-resident loop (sbm_langevin_run) vs the Python loop over the same kernels"}
         except Exception as exc:
             out["annealed_langevin"] = {"error": str(exc)[:200]}
+        try:
+            # classifier-guided conditional loop (sde_helper2.py:283-312, 65-94): modality 0 observed, one ClwithTime2 per (given, predicted) pair
+            from score_based_multimodal_autoencoder_amd.lat_sm2_model import ClwithTime2
+            mods = "".join(str(i) for i in range(W["n_mod"]))
+            cl = {f"0{j}": synth.fill_module_(ClwithTime2(n_mod=2, size_z=W["hw"] * W["hw"], n_class=1).eval()).to(device) for j in range(1, W["n_mod"])}
+            cond_sampler(z_obs, "0", score, sde, noise_obs=True, seed=12, cl_g=cl, cl_s=1.0, all_mods=mods)
+            t, _ = wall(lambda: cond_sampler(z_obs, "0", score, sde, noise_obs=True, seed=12, cl_g=cl, cl_s=1.0, all_mods=mods))
+            out["guided_cond_sampler"] = {"ms_per_sde_step": 1e3 * t / N_SDE, "note": "guidance of %d pairs per step; loop driven from Python over the HIP step kernels" % (W["n_mod"] - 1)}
+        except Exception as exc:
+            out["guided_cond_sampler"] = {"error": str(exc)[:200]}
+        try:
+            # DiffuseVAE refiner (eval_lat_celeba_hq_all.py:62-122, 448): the real UNetModel(6 -> 3) at 128x128, B = 64
+            from score_based_multimodal_autoencoder_amd.diffuse_vae import evaluate_diff_vae
+            from score_based_multimodal_autoencoder_amd.unet_openai import UNetModel
+            ref = synth.fill_module_(UNetModel(6, 128, 3, 2, (16,), 0.1, (1, 2, 2, 3, 4), num_heads=8).eval()).to(device)
+            vo = torch.rand(64, 3, 128, 128, device=device)
+            evaluate_diff_vae(vo, ref, device, timesteps=1, seed=14)
+            t, _ = wall(lambda: evaluate_diff_vae(vo, ref, device, timesteps=4, seed=14))
+            out["refiner"] = {"ms_per_ddpm_step": 1e3 * t / 4, "batch": 64, "note": "UNetModel(6,128,3,2,(16,),0.1,(1,2,2,3,4),num_heads=8) at 128x128 + fused ancestral update"}
+            ref.release_engines()
+        except Exception as exc:
+            out["refiner"] = {"error": str(exc)[:200]}
     return out
 
 

@@ -36,7 +36,9 @@ enum sbm_kind {
   SBM_RESDEC = 1,  /* h_vae_model_copy.ResVAE/ResAE/ResVAEN/ResAEN.decoder  h_vae_model_copy.py:123-126,166-169,489-492,576-579 */
   SBM_ATTRDEC = 2, /* h_vae_model.CelebAAttrNewBN[AE].decoder               h_vae_model.py:768-769,888-890 */
   SBM_UNET_OA = 3, /* unet_openai.UNetModel (conditional CelebA score net)   unet_openai.py:361-575 */
-  SBM_MLP = 4,     /* lat_sm2_model.LSMPoly64_sm (MLP score, DSM Langevin)   lat_sm2_model.py:348-371; cfg [n_mod, size_z] */
+  SBM_MLP = 4,     /* lat_sm2_model.LSMPoly64_sm (MLP score, DSM Langevin)   lat_sm2_model.py:348-371; cfg [n_mod, size_z].
+                    * RESTRICTION: n_mod * size_z must be a multiple of 32 (the GEMM's K granule; sbm_model_create fails otherwise).  The
+                    * reference accepts any width; its callers use 64-wide latents (n_mod * 64). */
   SBM_RESENC = 5   /* h_vae_model_copy.ResVAE/ResAE/ResVAEN/ResAEN.encoder: image (B,img_ch,s,s) -> (B, 2*size_z) = [mu | logvar]
                       h_vae_model_copy.py:41-71,379-409; cfg as SBM_RESDEC */,
   SBM_ATTRENC = 6  /* h_vae_model.CelebAAttrNewBN[AE].encoder: attributes (B, att_size) -> (B, 2*size_z) = [mu | logvar] (AE: (B, size_z))
