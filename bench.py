@@ -454,7 +454,7 @@ def main():
         uses_pix = bool(eng.info.get("uses_pix"))
         kern = {}
         for name, label, fl in (("seg_gemm", "seg_gemm<BM,BN> (fp32 MFMA implicit-GEMM conv, one launch per layer)", f_seg),
-                                ("pixrun_kernel", "pixrun_kernel (the 4x4, 2x2 and 1x1 levels as ONE launch of sample-owned workgroups: activations in LDS, weights streamed "
+                                ("pixrun_kernel", "pixrun_kernel (every level from 8x8 down as runs of sample-owned workgroups, one workgroup per sample: activations in LDS, weights streamed "
                                                   "from L2 in MFMA fragment order through an AGPR ring; fp32 MFMA 16x16x4 / 4x4x1 + dwconv/attention/GroupNorm glue)", f_chain if uses_pix else 0.0),
                                 ("chain_kernel", "chain_kernel (legacy: XCD-resident run of the 4x4 and 2x2 layers)", 0.0 if uses_pix else f_chain),
                                 ("rowrun_kernel", "rowrun_kernel (legacy: the 1x1 level, four samples per workgroup)", f_row)):
@@ -499,7 +499,7 @@ def main():
             "lib_hash": lib_hash(),
         }
         if uses_pix and "pixrun_kernel" in kern:
-            # the sample-owned kernel is bounded by two things at once: the matrix pipe on the 4x4 level and the L2 -> CU weight stream on
+            # the sample-owned kernel is bounded by two things at once: the matrix pipe on the 8x8 / 4x4 levels and the L2 -> CU weight stream on
             # the 2x2 / 1x1 levels (every workgroup reads every weight byte once per launch)
             mb = eng.info["pix_fragment_mb"]
             line["roofline"]["pixrun_weight_stream"] = {

@@ -24,6 +24,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -413,6 +414,7 @@ struct Builder {
 
 struct Program { RowOpD* d_ops = nullptr; RowEnt* d_ents = nullptr; int n_ops = 0; int act_floats = 0; };
 std::map<std::pair<const void*, long long>, Program> g_programs;   // (plan, first * 4096 + count) -> uploaded program
+std::mutex g_programs_mu;      // the map is process-wide (handles of different threads share it): every access holds this
 
 }  // namespace
 
@@ -422,6 +424,7 @@ size_t rowrun_lds_bytes(int act_floats) { return sizeof(float) * ((size_t)act_fl
 static const char* rowrun_build(const DevPlan& dp, int first, int count) {
   const Plan& plan = *dp.plan;
   const auto key = std::make_pair((const void*)&plan, (long long)first * 4096 + count);
+  std::lock_guard<std::mutex> lock(g_programs_mu);
   if (g_programs.count(key)) return nullptr;
   {
     auto fill = [&](Builder& b) -> const char* {
@@ -563,12 +566,16 @@ static const char* rowrun_build(const DevPlan& dp, int first, int count) {
 const char* launch_rowrun(const DevPlan& dp, int first, int count, hipStream_t st) {
   const Plan& plan = *dp.plan;
   const auto key = std::make_pair((const void*)&plan, (long long)first * 4096 + count);
-  auto it = g_programs.find(key);
-  if (it == g_programs.end()) {
+  Program p;
+  for (int attempt = 0;; ++attempt) {
+    {
+      std::lock_guard<std::mutex> lock(g_programs_mu);
+      auto it = g_programs.find(key);
+      if (it != g_programs.end()) { p = it->second; break; }
+    }
+    if (attempt) return "row kernel: program missing after build";
     if (const char* e = rowrun_build(dp, first, count)) return e;
-    it = g_programs.find(key);
   }
-  const Program& p = it->second;
   const int n_compute = (plan.B + ROW_R - 1) / ROW_R;
   const int n_prefetch = n_compute >= 8 ? 16 : 0;                    // two per XCD behind the compute workgroups (pure hint)
   const dim3 grid(n_compute + n_prefetch), block(RNT);
@@ -580,6 +587,7 @@ const char* launch_rowrun(const DevPlan& dp, int first, int count, hipStream_t s
 
 unsigned long long* g_row_dbg = nullptr;     // diagnostics only (sbm_debug_row_stamps)
 int rowrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap) {
+  std::lock_guard<std::mutex> lock(g_programs_mu);
   auto it = g_programs.find(std::make_pair((const void*)dp.plan, (long long)first * 4096 + count));
   if (it == g_programs.end()) return -1;
   std::vector<RowOpD> h(it->second.n_ops);
@@ -603,6 +611,7 @@ const char* rowrun_prepare(const DevPlan& dp) {
 
 // release the programs of a plan (model destruction)
 void rowrun_release(const Plan* plan) {
+  std::lock_guard<std::mutex> lock(g_programs_mu);
   for (auto it = g_programs.begin(); it != g_programs.end();) {
     if (it->first.first == (const void*)plan) { (void)hipFree(it->second.d_ops); (void)hipFree(it->second.d_ents); it = g_programs.erase(it); }
     else ++it;
