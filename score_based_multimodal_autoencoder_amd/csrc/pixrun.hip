@@ -659,7 +659,7 @@ struct PixState {
   std::map<int, PFragOp> fops;            // by plan op index
   std::map<long long, PProgram> programs; // by first * 4096 + count
   std::mutex mu;                          // programs are built on demand (debug sub-ranges); one handle may be driven from several host threads in the tests
-  const float* zero4 = nullptr;           // 4+ zero floats in the params arena
+  const float* zero4 = nullptr;           // zeros, as many as the widest op has columns (tail of the fragment arena)
 };
 
 namespace {
@@ -1034,14 +1034,17 @@ const char* pixrun_prepare(DevPlan& dp, const float* host_params, double* frag_m
   if (plan.ident_off < 0) return "pixel kernel: the plan has no zero vector";
   PixState* st = new (std::nothrow) PixState();
   if (!st) return "pixel kernel: out of host memory";
-  st->zero4 = dp.prm + plan.ident_off + 32;
   std::vector<float> arena;
+  int max_npad = 32;
   for (int i = 0; i < (int)plan.ops.size(); ++i) {
     const Op& op = plan.ops[i];
     if (!op.chain || op.time_path || op.kind != OP_GEMM) continue;
     if (const char* e = pix_gemm_supported(op.g)) { delete st; return e; }
     pack_fragments(host_params, op.g, &st->fops[i], &arena);
+    max_npad = std::max(max_npad, op.g.Npad);
   }
+  const size_t zero_off = arena.size();                    // a zero VECTOR as long as the widest op: absent bias / GroupNorm tables are read at any column
+  arena.resize(arena.size() + (size_t)max_npad + 64, 0.f);
   if (frag_mb) *frag_mb = arena.size() * 4.0 / 1e6;
   if (arena.size() > 0xffffffffull) { delete st; return "pixel kernel: fragment arena too large"; }
   static const double max_mb = std::getenv("SBM_PIX_MAX_MB") ? std::atof(std::getenv("SBM_PIX_MAX_MB")) : 48.0;
@@ -1051,6 +1054,7 @@ const char* pixrun_prepare(DevPlan& dp, const float* host_params, double* frag_m
   st->frag_floats = arena.size();
   if (hipMalloc(&st->d_frag, arena.size() * sizeof(float) + 4096) != hipSuccess) { delete st; return "pixel kernel: hipMalloc failed"; }
   if (hipMemcpy(st->d_frag, arena.data(), arena.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(st->d_frag); delete st; return "pixel kernel: hipMemcpy failed"; }
+  st->zero4 = st->d_frag + zero_off;
   ensure_dynamic_lds(reinterpret_cast<const void*>(pixrun_kernel), 160 * 1024);      // here, at model creation: per device and outside any stream capture
   dp.pix = st;
   for (int i = 0; i < (int)plan.ops.size();) {
