@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-N_GOLD, SHAPE = 10, (2, 3, 16, 16)
+N_GOLD, SHAPE = 50, (2, 3, 16, 16)
 
 
 @pytest.fixture(scope="module")
@@ -70,7 +70,7 @@ def _run_gold(pkg, g, tag, model, **kw):
     seed, count = g[tag + "_seed"]
     order, pc = tag.split("_")[1], tag.endswith("pc1")
     d = _draws(pkg, seed, count)
-    sde = pkg["sde"].VPSDE(0.1, 5.0, N_GOLD)       # beta_max 5: see make_golden.config45_cases
+    sde = pkg["sde"].VPSDE(0.1, 20.0, N_GOLD)      # the recipe's beta range (train_cel.sh:11), N = 50: see make_golden.config45_cases
     noise = torch.from_numpy(np.stack(d[1:])).cuda()
     return pkg["sde"].uncond_sampler(SHAPE, model, "cuda", sde, pc=pc, n_steps=1, target_snr=0.16, order=order, noise=noise,
                                      x0=torch.from_numpy(d[0]), **kw)
@@ -79,7 +79,7 @@ def _run_gold(pkg, g, tag, model, **kw):
 @pytest.mark.parametrize("order", ["cp", "pc"])
 @pytest.mark.parametrize("pc", [0, 1])
 def test_config4_loop_matches_reference(pkg, golden, score4, order, pc):
-    """sde_helper2.uncond_sampler (order cp) / calc_perf's predictor->corrector order around Unet(256, ch=3), N=10."""
+    """sde_helper2.uncond_sampler (order cp) / calc_perf's predictor->corrector order around Unet(256, ch=3), N=50, beta = (0.1, 20)."""
     g = golden("config45.npz")
     tag = f"c4_{order}_pc{pc}"
     want = g[tag + "_xmean"]
