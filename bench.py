@@ -259,9 +259,12 @@ def extra_measurements(cfg, score, decs, sde, x0, zc, device):
             from score_based_multimodal_autoencoder_amd.lat_sm2_model import ClwithTime2
             mods = "".join(str(i) for i in range(W["n_mod"]))
             cl = {f"0{j}": synth.fill_module_(ClwithTime2(n_mod=2, size_z=W["hw"] * W["hw"], n_class=1).eval()).to(device) for j in range(1, W["n_mod"])}
-            cond_sampler(z_obs, "0", score, sde, noise_obs=True, seed=12, cl_g=cl, cl_s=1.0, all_mods=mods)
-            t, _ = wall(lambda: cond_sampler(z_obs, "0", score, sde, noise_obs=True, seed=12, cl_g=cl, cl_s=1.0, all_mods=mods))
-            out["guided_cond_sampler"] = {"ms_per_sde_step": 1e3 * t / N_SDE, "note": "guidance of %d pairs per step; loop driven from Python over the HIP step kernels" % (W["n_mod"] - 1)}
+            gkw = dict(noise_obs=True, seed=12, cl_g=cl, cl_s=1.0, all_mods=mods)
+            cond_sampler(z_obs, "0", score, sde, **gkw)
+            t, _ = wall(lambda: cond_sampler(z_obs, "0", score, sde, **gkw))
+            t_py, _ = wall(lambda: cond_sampler(z_obs, "0", score, sde, fused_guidance=False, **gkw))
+            out["guided_cond_sampler"] = {"ms_per_sde_step": 1e3 * t / N_SDE, "python_loop_ms_per_sde_step": 1e3 * t_py / N_SDE,
+                                          "note": "guidance of the pairs '01' and '02' after every score evaluation; device-resident loop (sbm_guided_cond_sampler_run) vs the loop driven from Python over the same kernels"}
         except Exception as exc:
             out["guided_cond_sampler"] = {"error": str(exc)[:200]}
         try:

@@ -242,6 +242,16 @@ int sbm_cond_sampler_run(sbm_model* score, const sbm_sde_cfg* sde, const sbm_sam
                          const float* timesteps, const float* alphas, const float* noise, float* x_inout, float* x_mean_out,
                          int first_step, int n_run, float* elapsed_ms, void* stream);
 
+/* The same loop with classifier / energy guidance INSIDE the captured step: after every score evaluation -- the predictor's
+ * and each corrector iteration's -- every job subtracts cl_s * d cl_g(cat[x[:, ch1], x[:, ch2]], t).mean() / dx from the score of its two
+ * modalities (upd_mask bit 0 / 1: update ch1 / ch2), at the x and t of that evaluation: RSDE.sde sde_helper2.py:283-312 and corrector
+ * :65-94, pairs fixed for the run (the CelebA scripts' '01' / '02' / '12' form; the PolyMNIST variant draws a random pair per call on the
+ * host and stays a host-driven loop).  jobs[j].clg: an SBM_CLG handle (ClwithTime2 / ClwithTime3; id1 / id2 are used by variant 3). */
+typedef struct sbm_guide_job { sbm_model* clg; int ch1, ch2, id1, id2; unsigned upd_mask; } sbm_guide_job;
+int sbm_guided_cond_sampler_run(sbm_model* score, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const sbm_cond_cfg* cond, const float* z_obs,
+                                const sbm_guide_job* jobs, int n_jobs, float cl_s, const float* timesteps, const float* alphas, const float* noise,
+                                float* x_inout, float* x_mean_out, int first_step, int n_run, float* elapsed_ms, void* stream);
+
 /* Debug entry points used only by tests/tools: run the first n_ops ops of the plan (synchronises), read back
  * workspace floats, name an op ("<kind>:<reference layer>").  Not part of the drop-in surface. */
 int sbm_debug_forward_partial(sbm_model* m, const float* in_dev, const float* t_dev, float* out_dev, int n_ops, void* stream);

@@ -22,7 +22,7 @@ OP_KIND_NAMES = ["seg_gemm", "dwconv7", "linattn", "attn", "gn_res", "sinus", "n
 
 EXPORTS = ["sbm_last_error", "sbm_abi_version", "sbm_spec_count", "sbm_spec", "sbm_model_create", "sbm_model_destroy", "sbm_model_check",
            "sbm_model_info", "sbm_model_note", "sbm_model_forward", "sbm_model_forward_aux", "sbm_model_set_aux", "sbm_model_profile", "sbm_model_profile_mix", "sbm_model_gemm_flops", "sbm_em_step", "sbm_langevin_step", "sbm_langevin_norms", "sbm_langevin_update", "sbm_clg_forward", "sbm_clg_guide",
-           "sbm_fill_normal", "sbm_sampler_run", "sbm_cond_sampler_run", "sbm_langevin_fixed_step", "sbm_langevin_run", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
+           "sbm_fill_normal", "sbm_sampler_run", "sbm_cond_sampler_run", "sbm_guided_cond_sampler_run", "sbm_langevin_fixed_step", "sbm_langevin_run", "sbm_renoise_observed", "sbm_debug_forward_partial", "sbm_debug_forward_range", "sbm_debug_workspace_floats",
            "sbm_debug_read_workspace", "sbm_debug_op_name", "sbm_debug_profile_ops", "sbm_debug_gemm_stamps", "sbm_debug_chain_sync", "sbm_debug_chain_ctl", "sbm_debug_chain_stamps", "sbm_debug_row_stamps", "sbm_debug_pix_stamps",
            "sbm_ddpm_step", "sbm_fid_accumulate", "sbm_fid_finalize_stats", "sbm_fid_work_doubles", "sbm_fid_frechet", "sbm_debug_dgemm_tn"]
 
@@ -34,6 +34,11 @@ class SdeCfg(ctypes.Structure):
 
 class CondCfg(ctypes.Structure):
     _fields_ = [("obs_mask", ctypes.c_uint), ("noise_obs", ctypes.c_int), ("n_mod", ctypes.c_int)]
+
+
+class GuideJob(ctypes.Structure):
+    _fields_ = [("clg", ctypes.c_void_p), ("ch1", ctypes.c_int), ("ch2", ctypes.c_int), ("id1", ctypes.c_int), ("id2", ctypes.c_int),
+                ("upd_mask", ctypes.c_uint)]
 
 
 class SamplerCfg(ctypes.Structure):
@@ -116,6 +121,8 @@ def lib():
                                       ctypes.POINTER(ctypes.c_float), vp]
         L.sbm_cond_sampler_run.argtypes = [vp, ctypes.POINTER(SdeCfg), ctypes.POINTER(SamplerCfg), ctypes.POINTER(CondCfg), vp, vp, vp, vp, vp, vp, i, i,
                                            ctypes.POINTER(ctypes.c_float), vp]
+        L.sbm_guided_cond_sampler_run.argtypes = [vp, ctypes.POINTER(SdeCfg), ctypes.POINTER(SamplerCfg), ctypes.POINTER(CondCfg), vp,
+                                                  ctypes.POINTER(GuideJob), i, ctypes.c_float, vp, vp, vp, vp, vp, i, i, ctypes.POINTER(ctypes.c_float), vp]
         L.sbm_debug_forward_partial.argtypes = [vp, vp, vp, vp, i, vp]
         L.sbm_debug_forward_range.argtypes = [vp, vp, vp, vp, i, i, vp]
         L.sbm_debug_workspace_floats.restype = ctypes.c_long

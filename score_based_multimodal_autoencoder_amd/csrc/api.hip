@@ -687,14 +687,21 @@ int sbm_langevin_step(const sbm_sde_cfg* sde, const float* x, const float* score
 }
 
 // ---- classifier / energy guidance ----
-static int clg_run(sbm_model* m, ClgArgs a, void* stream, const char* who) {
+// the guidance network's weights and shape into a launch argument block (pointers stay valid while the handle lives)
+static int clg_bind(sbm_model* m, ClgArgs* pa, const char* who) {
+  ClgArgs& a = *pa;
   if (!m || m->kind != SBM_CLG) return fail(std::string(who) + ": not a guidance model handle");
-  if (!a.t || a.B <= 0) return fail(std::string(who) + ": bad arguments");
   const float* p = m->d_params; const long long* o = m->clg_off;
   a.Wt_T = p + o[0]; a.bt = p + o[1]; a.emb = o[2] >= 0 ? p + o[2] : nullptr; a.W1 = p + o[3]; a.W1_T = p + o[4]; a.b1 = p + o[5];
   a.W2 = p + o[6]; a.W2_T = p + o[7]; a.b2 = p + o[8]; a.W3 = p + o[9]; a.b3 = p + o[10]; a.freq = p + o[11];
   a.D0 = (int)o[12]; a.size_z = m->clg_cfg[2]; a.n_class = m->clg_cfg[3]; a.n_emb = m->clg_cfg[0] == 3 ? 1 : 0;
   if (a.n_emb && (a.id1 < 0 || a.id1 >= 10 || a.id2 < 0 || a.id2 >= 10)) return fail(std::string(who) + ": modality ids must be in [0, 10)");
+  return 0;
+}
+
+static int clg_run(sbm_model* m, ClgArgs a, void* stream, const char* who) {
+  if (!a.t || a.B <= 0) return fail(std::string(who) + ": bad arguments");
+  if (int rc = clg_bind(m, &a, who)) return rc;
   const char* e = launch_clg(a, (hipStream_t)stream);
   if (e) return fail(std::string(who) + ": " + e);
   HIPCHK(hipGetLastError());
@@ -779,7 +786,8 @@ int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_
 
 // one full sampling step enqueued on `st` (graph-capturable: no allocation, no sync, step index read on device)
 static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sampler_cfg& c, const float* timesteps, const float* alphas, const float* noise,
-                                float* x, float* x_mean, hipStream_t st, bool time_table, const sbm_cond_cfg* cond = nullptr, const float* z_obs = nullptr) {
+                                float* x, float* x_mean, hipStream_t st, bool time_table, const sbm_cond_cfg* cond = nullptr, const float* z_obs = nullptr,
+                                const std::vector<ClgArgs>* guide = nullptr) {
   const Plan& P = m->plan;
   const int B = P.B, CHW = P.out_C * P.out_H * P.out_W;
   const int dps = 1 + (c.pc ? c.n_steps : 0);
@@ -788,10 +796,20 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
   a.x = x; a.score = m->d_score; a.noise = noise; a.t = nullptr; a.timesteps = timesteps; a.step_counter = m->d_counter; a.alphas = alphas;
   a.x_out = x; a.mean_out = x_mean; a.norms = m->d_norms; a.seed = c.seed; a.sample_offset = c.sample_offset; a.B = B; a.CHW = CHW; a.sde = sp;
   a.noise_step_stride = (long long)dps * B * CHW;
+  const bool guided = guide && !guide->empty();
   auto score_eval = [&]() -> const char* {
-    if (time_table) return run_plan(m->dp, x, tbuf, m->d_score, st, 1);     // the time path comes from the table
-    launch_fill_time(tbuf, timesteps, m->d_counter, B, st);
-    return run_plan(m->dp, x, tbuf, m->d_score, st);
+    const char* e;
+    if (time_table) {
+      if (guided) launch_fill_time(tbuf, timesteps, m->d_counter, B, st);   // the guidance networks take the step's time per sample (the score net reads the table)
+      e = run_plan(m->dp, x, tbuf, m->d_score, st, 1);                      // the time path comes from the table
+    } else {
+      launch_fill_time(tbuf, timesteps, m->d_counter, B, st);
+      e = run_plan(m->dp, x, tbuf, m->d_score, st);
+    }
+    if (e) return e;
+    if (guided)                    // classifier / energy guidance on the score just evaluated, at the same x and t (sde_helper2.py:283-312, 65-94)
+      for (ClgArgs a : *guide) { a.x = x; a.t = tbuf; a.score = m->d_score; if ((e = launch_clg(a, st))) return e; }
+    return nullptr;
   };
   auto corrector = [&](int first_draw) -> const char* {
     for (int i = 0; i < c.n_steps; ++i) {
@@ -862,7 +880,7 @@ static int build_time_table(sbm_model* m, const float* times_dev, int N, const f
 
 static int sampler_run_impl(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const sbm_cond_cfg* cond, const float* z_obs,
                             const float* timesteps, const float* alphas, const float* noise, float* x_inout, float* x_mean_out, int first_step,
-                            int n_run, float* elapsed_ms, void* stream) {
+                            int n_run, float* elapsed_ms, void* stream, const std::vector<ClgArgs>* guide = nullptr) {
   if (!m || (m->kind != SBM_UNET && m->kind != SBM_UNET_OA) || !sde || !cfg || !timesteps || !x_inout || !x_mean_out) return fail("sbm_sampler_run: bad arguments");
   if (cond) {
     if (!z_obs || cond->n_mod <= 0 || cond->n_mod > 32 || cond->n_mod != m->plan.out_C) return fail("sbm_cond_sampler_run: n_mod must equal the score net's channel count; z_obs must be given");
@@ -897,7 +915,7 @@ static int sampler_run_impl(sbm_model* m, const sbm_sde_cfg* sde, const sbm_samp
   }
   if (cfg->use_graph && n_run > 1) {
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table, cond, z_obs);
+    e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table, cond, z_obs, guide);
     hipError_t ce = hipStreamEndCapture(st, &graph);
     if (e) return fail(std::string("sbm_sampler_run: ") + e);
     if (ce != hipSuccess) return fail_hip("hipStreamEndCapture", ce);
@@ -906,7 +924,7 @@ static int sampler_run_impl(sbm_model* m, const sbm_sde_cfg* sde, const sbm_samp
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t0, st));
   for (int i = 0; i < n_run; ++i) {
     if (exec) { hipError_t le = hipGraphLaunch(exec, st); if (le != hipSuccess) return fail_hip("hipGraphLaunch", le); }
-    else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table, cond, z_obs))) return fail(std::string("sbm_sampler_run: ") + e);
+    else if ((e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table, cond, z_obs, guide))) return fail(std::string("sbm_sampler_run: ") + e);
   }
   if (cond && n_run > 0) {                 // the observed modalities leave as their clean latents (:314-316 keep z[mod] for mod in given)
     StepArgs r{};
@@ -941,6 +959,29 @@ int sbm_cond_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler
                          int n_run, float* elapsed_ms, void* stream) {
   if (!cond) return fail("sbm_cond_sampler_run: bad arguments");
   return sampler_run_impl(m, sde, cfg, cond, z_obs, timesteps, alphas, noise, x_inout, x_mean_out, first_step, n_run, elapsed_ms, stream);
+}
+
+// The conditional loop with classifier / energy guidance inside the captured step: after EVERY score evaluation (predictor and each
+// corrector iteration) the listed guidance networks subtract cl_s * d cl_g(cat[x_m1, x_m2], t).mean() / dx from the score slices of
+// their pair, at the x and t of that evaluation -- sde_helper2.py:283-312 (RSDE.sde) and :65-94 (corrector).
+int sbm_guided_cond_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_sampler_cfg* cfg, const sbm_cond_cfg* cond, const float* z_obs,
+                                const sbm_guide_job* jobs, int n_jobs, float cl_s, const float* timesteps, const float* alphas, const float* noise,
+                                float* x_inout, float* x_mean_out, int first_step, int n_run, float* elapsed_ms, void* stream) {
+  if (!m || !cond || !jobs || n_jobs <= 0 || n_jobs > 64) return fail("sbm_guided_cond_sampler_run: bad arguments");
+  const int C = m->plan.out_C, per_mod = m->plan.out_H * m->plan.out_W;
+  std::vector<ClgArgs> guide((size_t)n_jobs);
+  for (int j = 0; j < n_jobs; ++j) {
+    const sbm_guide_job& jb = jobs[j];
+    ClgArgs& a = guide[(size_t)j];
+    a = ClgArgs{};
+    if (!jb.clg || jb.clg->kind != SBM_CLG) return fail("sbm_guided_cond_sampler_run: job without a guidance model handle");
+    if (per_mod != jb.clg->clg_cfg[2]) return fail("sbm_guided_cond_sampler_run: a modality's latent size must equal the guidance MLP's size_z");
+    if (jb.ch1 < 0 || jb.ch1 >= C || jb.ch2 < 0 || jb.ch2 >= C) return fail("sbm_guided_cond_sampler_run: modality channel out of range");
+    a.C = C; a.per_mod = per_mod; a.ch1 = jb.ch1; a.ch2 = jb.ch2; a.id1 = jb.id1; a.id2 = jb.id2; a.cl_s = cl_s; a.upd_mask = jb.upd_mask; a.B = m->plan.B;
+    if (int rc = clg_bind(jb.clg, &a, "sbm_guided_cond_sampler_run")) return rc;
+  }
+  clg_prepare();
+  return sampler_run_impl(m, sde, cfg, cond, z_obs, timesteps, alphas, noise, x_inout, x_mean_out, first_step, n_run, elapsed_ms, stream, &guide);
 }
 
 // Device-resident annealed-Langevin loop (fid_upd10.gen_ae :84-99, eval_lat_celeba_hq_all.evaluate :258-275): n_iter iterations of

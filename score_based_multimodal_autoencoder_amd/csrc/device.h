@@ -216,6 +216,7 @@ struct ClgArgs {
   int B, size_z, n_class, D0, n_emb;
 };
 const char* launch_clg(const ClgArgs& a, hipStream_t st);
+void clg_prepare();
 std::vector<TensorSpec> clg_tensor_specs(int variant, int n_mod, int size_z, int n_class);
 bool clg_pack(int variant, int n_mod, int size_z, int n_class, const float* const* t, std::vector<float>* out, long long* off, std::string* err);
 

@@ -175,6 +175,9 @@ __global__ __launch_bounds__(CLG_NT) void clg_kernel(const ClgArgs a) {
 
 size_t clg_lds_bytes(int D0) { return sizeof(float) * CLG_TS * (size_t)(D0 + 2 * CLG_H1 + 2 * CLG_H2 + CLG_TE); }
 
+// once per device, outside any stream capture (the fused guided loop calls it before it captures its step)
+void clg_prepare() { ensure_dynamic_lds(reinterpret_cast<const void*>(clg_kernel), 160 * 1024); }
+
 const char* launch_clg(const ClgArgs& a, hipStream_t st) {
   const size_t lds = clg_lds_bytes(a.D0);
   if (lds > 160 * 1024) return "guidance: the input width does not fit the LDS tile";

@@ -207,6 +207,25 @@ def apply_guidance_(x, t, score, cl_g, cl_s, given, all_mods, poly_pairs=False):
     return score
 
 
+def _guide_jobs(cl_g, cl_s, given, all_mods, x):
+    """The (network, channel 1, channel 2) list of apply_guidance_ for a fixed-pair run, or None when the run cannot be fused (a
+    network that is not this package's HIP module, no scale, no modality names)."""
+    from .lat_sm2_model import _ClwithTime
+    if cl_s is None or all_mods is None or not isinstance(cl_g, dict):
+        return None
+    base = int(all_mods[0])
+    gstr = "".join(all_mods[m] for m in given)
+    predicted = "".join(m for m in all_mods if m not in gstr)
+    jobs = []
+    for m1, m2 in (("0", "1"), ("0", "2"), ("1", "2")):
+        if (m1 in gstr and m2 in predicted) or (m2 in gstr and m1 in predicted):
+            net = cl_g[m1 + m2]
+            if not isinstance(net, _ClwithTime) or net.size_z != x[0, 0].numel():
+                return None
+            jobs.append((net, int(m1) - base, int(m2) - base))
+    return jobs or None
+
+
 def _guided(cl_g, given):
     return cl_g is not None and given is not None and bool(given)
 
@@ -426,15 +445,17 @@ def renoise_observed(x, z_obs, t, sde, given, out=None):
 
 def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target_snr=0.16, noise_obs=False, *, x0=None, noise=None,
                  z_cond=None, cl_g=None, cl_s=None, all_mods=None, poly_pairs=False, seed=None, sample_offset=0, use_graph=True,
-                 return_timing=False):
+                 return_timing=False, fused_guidance=True):
     """Conditional generation loop of the training scripts' evaluators (train_poly_unet_cont.evaluate :340-381,
     train_lat_celebhq_unet_cont2.calc_perf :277-318): channels in `given` hold the observed latents z_obs (re-noised to level t at
     every step when noise_obs), the others start from N(0,1) (or x0) and follow the reverse SDE, predictor then corrector.
     Returns the joint state (B, n_mod, H, W): unobserved channels = final x_mean, observed = clean z_obs.
 
-    With this package's score nets and no guidance the whole loop runs on the device as ONE captured step replayed N times
-    (`sbm_cond_sampler_run`: re-noise + score + predictor [+ corrector] + write-back); otherwise (a generic score callable, or
-    `cl_g` guidance with `all_mods` naming the modalities, e.g. '012') the loop is driven from Python over the same HIP step kernels.
+    With this package's score nets the whole loop runs on the device as ONE captured step replayed N times (`sbm_cond_sampler_run`:
+    re-noise + score + predictor [+ corrector] + write-back), also under `cl_g` guidance when every guidance network is this package's
+    `ClwithTime2/3` and the pairs are fixed (`all_mods` naming the modalities, e.g. '012': `sbm_guided_cond_sampler_run`).  A generic
+    score callable, a user's own torch guidance module, the PolyMNIST random-pair variant (`poly_pairs`) or `fused_guidance=False` drive
+    the loop from Python over the same HIP step kernels.
     noise: injected draws [(N * (1 + pc * n_steps)), B, n_mod, H, W] in execution order (parity tests); default in-kernel Philox
     (fused) / torch.randn_like (generic)."""
     z_obs = as_f32_cuda(z_obs, "z_obs")
@@ -457,7 +478,8 @@ def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target
             if noise.shape[0] < sde.N * dps:
                 raise ValueError(f"noise needs {sde.N * dps} draws")
         guided = cl_g is not None and len(given) > 0
-        if _fused_ok(model, z_cond) and not guided:
+        jobs = _guide_jobs(cl_g, cl_s, given, all_mods, x) if guided and not poly_pairs and fused_guidance else None
+        if _fused_ok(model, z_cond) and (not guided or jobs is not None):
             from .unet_openai import UNetModel
             if isinstance(model, UNetModel):
                 eng = model._engine_for(B, x.shape[2], x.shape[3], z_cond is not None)
@@ -471,10 +493,19 @@ def cond_sampler(z_obs, given, model, sde, eps=1e-3, pc=False, n_steps=1, target
             alphas = _alphas_dev(sde, device) if pc else None
             x_mean = torch.empty_like(x)
             ms = ctypes.c_float(0.0)
-            _lib.check(_lib.lib().sbm_cond_sampler_run(eng.h, ctypes.byref(cfg), ctypes.byref(scfg), ctypes.byref(ccfg), z_obs.data_ptr(),
-                                                       timesteps.data_ptr(), alphas.data_ptr() if alphas is not None else None,
-                                                       noise.data_ptr() if noise is not None else None, x.data_ptr(), x_mean.data_ptr(), 0,
-                                                       sde.N, ctypes.byref(ms) if return_timing else None, _lib.stream_ptr()))
+            if jobs:
+                # guidance inside the captured step (sbm_guided_cond_sampler_run): the same clg kernel after every score evaluation
+                arr = (_lib.GuideJob * len(jobs))(*[_lib.GuideJob(net._engine_for().h, c1, c2, c1, c2, 3) for net, c1, c2 in jobs])
+                _lib.check(_lib.lib().sbm_guided_cond_sampler_run(eng.h, ctypes.byref(cfg), ctypes.byref(scfg), ctypes.byref(ccfg), z_obs.data_ptr(),
+                                                                  arr, len(jobs), ctypes.c_float(float(cl_s)), timesteps.data_ptr(),
+                                                                  alphas.data_ptr() if alphas is not None else None,
+                                                                  noise.data_ptr() if noise is not None else None, x.data_ptr(), x_mean.data_ptr(), 0,
+                                                                  sde.N, ctypes.byref(ms) if return_timing else None, _lib.stream_ptr()))
+            else:
+                _lib.check(_lib.lib().sbm_cond_sampler_run(eng.h, ctypes.byref(cfg), ctypes.byref(scfg), ctypes.byref(ccfg), z_obs.data_ptr(),
+                                                           timesteps.data_ptr(), alphas.data_ptr() if alphas is not None else None,
+                                                           noise.data_ptr() if noise is not None else None, x.data_ptr(), x_mean.data_ptr(), 0,
+                                                           sde.N, ctypes.byref(ms) if return_timing else None, _lib.stream_ptr()))
             return (x_mean, ms.value) if return_timing else x_mean
         gstr = None
         if guided:

@@ -122,3 +122,33 @@ def test_any_torch_callable_is_accepted_like_the_reference(pkg, golden):
     b = S.apply_guidance_(x, t, score.clone(), {"01": Plain(hip)}, 2000.0, "0", "01")
     assert float((a - score).abs().max()) > 1e-3
     assert_close(a.cpu().numpy(), b.cpu().numpy(), 1e-4, 1e-5 * float(a.abs().max()), "HIP VJP vs torch.autograd")
+
+
+@pytest.mark.parametrize("pc", [False, True])
+@pytest.mark.parametrize("given", [[0], [0, 2]])
+def test_guided_conditional_loop_on_the_device_equals_the_host_driven_loop(pkg, given, pc):
+    """the guided conditional loop as ONE captured step replayed N times (sbm_guided_cond_sampler_run: re-noise, score net,
+    guidance kernels, predictor [, score net, guidance, corrector]) against the same loop driven from Python, call by call, over the same
+    kernels -- injected noise, so the two see the same draws.  The guidance must matter (the unguided run differs)."""
+    from score_based_multimodal_autoencoder_amd.unet_model import Unet
+    S = pkg["sde"]
+    unet = pkg["synth"].fill_module_(Unet(dim=8, channels=3, dim_mults=(1, 2, 2, 2)).eval()).cuda()
+    cl = {k: _filled(pkg, pkg["lm"].ClwithTime2, "clg" + k, n_mod=2, size_z=64, n_class=1) for k in ("01", "02", "12")}
+    N, B = 12, 4
+    sde = S.VPSDE(0.1, 5.0, N)
+    z_obs = torch.randn(B, 3, 8, 8, device="cuda")
+    x0 = torch.randn(B, 3, 8, 8, device="cuda")
+    noise = torch.randn(N * (2 if pc else 1), B, 3, 8, 8, device="cuda")
+    kw = dict(pc=pc, n_steps=1, noise_obs=True, x0=x0, noise=noise, cl_g=cl, cl_s=500.0, all_mods="012")
+    a = S.cond_sampler(z_obs, given, unet, sde, **kw)
+    b = S.cond_sampler(z_obs, given, unet, sde, fused_guidance=False, **kw)
+    plain = S.cond_sampler(z_obs, given, unet, sde, pc=pc, n_steps=1, noise_obs=True, x0=x0, noise=noise)
+    assert torch.isfinite(a).all()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 1e-5 * scale, float((a - b).abs().max())
+    assert float((a - plain).abs().max()) > 1e-3 * scale, "the guidance must change the trajectory"
+    for m in given:
+        assert torch.equal(a[:, m], z_obs[:, m])                                   # observed modalities leave as their clean latents
+    # the graph and the eager form of the fused loop agree bit for bit
+    c = S.cond_sampler(z_obs, given, unet, sde, use_graph=False, **kw)
+    assert torch.equal(a, c)
