@@ -29,21 +29,66 @@ namespace sbm {
 namespace {
 
 constexpr int CLG_TS = 8;        // samples per workgroup
-constexpr int CLG_NT = 256;
+constexpr int CLG_NT = 1024;     // threads: every mat-vec phase is cut into (output neuron) x (K slice) tasks, so that a thread's serial,
+                                 // load-latency-bound K loop is 64 ... 128 long instead of 256 ... 512 (r03: 130 -> see DESIGN 6c)
 constexpr int CLG_TE = 64, CLG_TH = 128, CLG_EMB = 32, CLG_H1 = 512, CLG_H2 = 256;
+constexpr int CLG_PART = CLG_NT * CLG_TS;      // partial sums [K slice][output][sample]
 
 __device__ __forceinline__ float softplus_f(float v) { return v > 20.f ? v : log1pf(expf(v)); }            // nn.Softplus(beta=1, threshold=20)
 __device__ __forceinline__ float dsoftplus_f(float v) { if (v > 20.f) return 1.f; const float z = expf(v); return z / (z + 1.0f); }   // its backward
 
+// One mat-vec phase for the workgroup's TS samples: out[n][s] = sum_k w(k, n) * in[k][s], n < outs, k < K.  Thread (n, slice) walks its
+// K slice (consecutive threads read consecutive weights), the slices meet in `part` and are added in slice order by thread n, which
+// hands the sums to `fin(n, acc)`.  Two barriers per phase.
+template <class W, class F>
+__device__ __forceinline__ void clg_phase(int outs, int K, const float* in, float* part, W w, F fin) {
+  const int tid = threadIdx.x;
+  int ksn = 1;
+  while (ksn * 2 * outs <= CLG_NT && ksn * 2 <= K) ksn *= 2;
+  for (int n0 = 0; n0 < outs; n0 += CLG_NT) {                 // (outs <= CLG_NT for every layer of this network: one round)
+    const int cnt = outs - n0 < CLG_NT ? outs - n0 : CLG_NT;
+    const int n = tid % cnt, ks = tid / cnt;
+    if (ks < ksn) {
+      float acc[CLG_TS];
+#pragma unroll
+      for (int s = 0; s < CLG_TS; ++s) acc[s] = 0.f;
+      const int k0 = (int)((long long)K * ks / ksn), k1 = (int)((long long)K * (ks + 1) / ksn);
+#pragma unroll 4
+      for (int k = k0; k < k1; ++k) {
+        const float wv = w(k, n0 + n);
+        const float4 v0 = *reinterpret_cast<const float4*>(in + k * CLG_TS), v1 = *reinterpret_cast<const float4*>(in + k * CLG_TS + 4);
+        acc[0] = fmaf(wv, v0.x, acc[0]); acc[1] = fmaf(wv, v0.y, acc[1]); acc[2] = fmaf(wv, v0.z, acc[2]); acc[3] = fmaf(wv, v0.w, acc[3]);
+        acc[4] = fmaf(wv, v1.x, acc[4]); acc[5] = fmaf(wv, v1.y, acc[5]); acc[6] = fmaf(wv, v1.z, acc[6]); acc[7] = fmaf(wv, v1.w, acc[7]);
+      }
+      float4* pp = reinterpret_cast<float4*>(part + ((long long)ks * cnt + n) * CLG_TS);
+      pp[0] = make_float4(acc[0], acc[1], acc[2], acc[3]); pp[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+    __syncthreads();
+    if (tid < cnt) {
+      float acc[CLG_TS];
+#pragma unroll
+      for (int s = 0; s < CLG_TS; ++s) acc[s] = 0.f;
+      for (int q = 0; q < ksn; ++q) {
+        const float4* pp = reinterpret_cast<const float4*>(part + ((long long)q * cnt + tid) * CLG_TS);
+        const float4 v0 = pp[0], v1 = pp[1];
+        acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w; acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+      }
+      fin(n0 + tid, acc);
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(CLG_NT) void clg_kernel(const ClgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  // LDS: a0 [D0][TS] | a1 [H1][TS] | s1 [H1][TS] | a2 [H2][TS] | s2 [H2][TS] | te [TE][TS]
+  // LDS: a0 [D0][TS] | a1 [H1][TS] | s1 [H1][TS] | a2 [H2][TS] | s2 [H2][TS] | te [TE][TS] | part [NT][TS]
   float* a0 = sm;
   float* a1 = a0 + a.D0 * CLG_TS;
   float* s1 = a1 + CLG_H1 * CLG_TS;
   float* a2 = s1 + CLG_H1 * CLG_TS;
   float* s2 = a2 + CLG_H2 * CLG_TS;
   float* te = s2 + CLG_H2 * CLG_TS;
+  float* part = te + CLG_TE * CLG_TS;
   const int tid = threadIdx.x, b0 = blockIdx.x * CLG_TS;
   const int nx = 2 * a.size_z;
   // ---- inputs: the two latent slices, the sinusoid of t, the modality embeddings
@@ -66,49 +111,25 @@ __global__ __launch_bounds__(CLG_NT) void clg_kernel(const ClgArgs a) {
   }
   __syncthreads();
   // ---- time MLP: temb = softplus(Wt te + bt) -> a0[nx .. nx + TH)
-  for (int n = tid; n < CLG_TH; n += CLG_NT) {
-    float acc[CLG_TS];
+  clg_phase(CLG_TH, CLG_TE, te, part, [&](int k, int n) { return a.Wt_T[k * CLG_TH + n]; },
+            [&](int n, const float* acc) {
 #pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) acc[s] = a.bt[n];
-    for (int k = 0; k < CLG_TE; ++k) {
-      const float w = a.Wt_T[k * CLG_TH + n];
-#pragma unroll
-      for (int s = 0; s < CLG_TS; ++s) acc[s] = fmaf(w, te[k * CLG_TS + s], acc[s]);
-    }
-#pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) a0[(nx + n) * CLG_TS + s] = softplus_f(acc[s]);
-  }
-  __syncthreads();
+              for (int s = 0; s < CLG_TS; ++s) a0[(nx + n) * CLG_TS + s] = softplus_f(acc[s] + a.bt[n]);
+            });
   // ---- layer 1: D0 -> 512
-  for (int n = tid; n < CLG_H1; n += CLG_NT) {
-    float acc[CLG_TS];
+  clg_phase(CLG_H1, a.D0, a0, part, [&](int k, int n) { return a.W1_T[(long long)k * CLG_H1 + n]; },
+            [&](int n, const float* acc) {
+              const float bb = a.b1[n];
 #pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) acc[s] = a.b1[n];
-    for (int k = 0; k < a.D0; ++k) {
-      const float w = a.W1_T[(long long)k * CLG_H1 + n];
-      const float4 v0 = *reinterpret_cast<const float4*>(a0 + k * CLG_TS), v1 = *reinterpret_cast<const float4*>(a0 + k * CLG_TS + 4);
-      acc[0] = fmaf(w, v0.x, acc[0]); acc[1] = fmaf(w, v0.y, acc[1]); acc[2] = fmaf(w, v0.z, acc[2]); acc[3] = fmaf(w, v0.w, acc[3]);
-      acc[4] = fmaf(w, v1.x, acc[4]); acc[5] = fmaf(w, v1.y, acc[5]); acc[6] = fmaf(w, v1.z, acc[6]); acc[7] = fmaf(w, v1.w, acc[7]);
-    }
-#pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) { a1[n * CLG_TS + s] = softplus_f(acc[s]); s1[n * CLG_TS + s] = dsoftplus_f(acc[s]); }
-  }
-  __syncthreads();
+              for (int s = 0; s < CLG_TS; ++s) { a1[n * CLG_TS + s] = softplus_f(acc[s] + bb); s1[n * CLG_TS + s] = dsoftplus_f(acc[s] + bb); }
+            });
   // ---- layer 2: 512 -> 256
-  for (int n = tid; n < CLG_H2; n += CLG_NT) {
-    float acc[CLG_TS];
+  clg_phase(CLG_H2, CLG_H1, a1, part, [&](int k, int n) { return a.W2_T[k * CLG_H2 + n]; },
+            [&](int n, const float* acc) {
+              const float bb = a.b2[n];
 #pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) acc[s] = a.b2[n];
-    for (int k = 0; k < CLG_H1; ++k) {
-      const float w = a.W2_T[k * CLG_H2 + n];
-      const float4 v0 = *reinterpret_cast<const float4*>(a1 + k * CLG_TS), v1 = *reinterpret_cast<const float4*>(a1 + k * CLG_TS + 4);
-      acc[0] = fmaf(w, v0.x, acc[0]); acc[1] = fmaf(w, v0.y, acc[1]); acc[2] = fmaf(w, v0.z, acc[2]); acc[3] = fmaf(w, v0.w, acc[3]);
-      acc[4] = fmaf(w, v1.x, acc[4]); acc[5] = fmaf(w, v1.y, acc[5]); acc[6] = fmaf(w, v1.z, acc[6]); acc[7] = fmaf(w, v1.w, acc[7]);
-    }
-#pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) { a2[n * CLG_TS + s] = softplus_f(acc[s]); s2[n * CLG_TS + s] = dsoftplus_f(acc[s]); }
-  }
-  __syncthreads();
+              for (int s = 0; s < CLG_TS; ++s) { a2[n * CLG_TS + s] = softplus_f(acc[s] + bb); s2[n * CLG_TS + s] = dsoftplus_f(acc[s] + bb); }
+            });
   // ---- layer 3: 256 -> n_class (forward output, when asked for)
   if (a.out) {
     for (int idx = tid; idx < a.n_class * CLG_TS; idx += CLG_NT) {
@@ -132,48 +153,31 @@ __global__ __launch_bounds__(CLG_NT) void clg_kernel(const ClgArgs a) {
   }
   __syncthreads();
   //      g1 = (W2^T g2) * sigmoid(pre1)                -> overwrites a1
-  for (int k = tid; k < CLG_H1; k += CLG_NT) {
-    float acc[CLG_TS];
+  clg_phase(CLG_H1, CLG_H2, a2, part, [&](int n, int k) { return a.W2[n * CLG_H1 + k]; },
+            [&](int k, const float* acc) {
 #pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) acc[s] = 0.f;
-    for (int n = 0; n < CLG_H2; ++n) {
-      const float w = a.W2[n * CLG_H1 + k];
-      const float4 v0 = *reinterpret_cast<const float4*>(a2 + n * CLG_TS), v1 = *reinterpret_cast<const float4*>(a2 + n * CLG_TS + 4);
-      acc[0] = fmaf(w, v0.x, acc[0]); acc[1] = fmaf(w, v0.y, acc[1]); acc[2] = fmaf(w, v0.z, acc[2]); acc[3] = fmaf(w, v0.w, acc[3]);
-      acc[4] = fmaf(w, v1.x, acc[4]); acc[5] = fmaf(w, v1.y, acc[5]); acc[6] = fmaf(w, v1.z, acc[6]); acc[7] = fmaf(w, v1.w, acc[7]);
-    }
-#pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) a1[k * CLG_TS + s] = acc[s] * s1[k * CLG_TS + s];
-  }
-  __syncthreads();
+              for (int s = 0; s < CLG_TS; ++s) a1[k * CLG_TS + s] = acc[s] * s1[k * CLG_TS + s];
+            });
   //      gx = W1[:, :2 size_z]^T g1 ; score[:, m] -= cl_s * gx
-  for (int j = tid; j < nx; j += CLG_NT) {
-    float acc[CLG_TS];
+  clg_phase(nx, CLG_H1, a1, part, [&](int k, int j) { return a.W1[(long long)k * a.D0 + j]; },
+            [&](int j, const float* acc) {
+              const int half = j < a.size_z ? 0 : 1, e = j - half * a.size_z, ch = half ? a.ch2 : a.ch1;
 #pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) acc[s] = 0.f;
-    for (int k = 0; k < CLG_H1; ++k) {
-      const float w = a.W1[(long long)k * a.D0 + j];
-      const float4 v0 = *reinterpret_cast<const float4*>(a1 + k * CLG_TS), v1 = *reinterpret_cast<const float4*>(a1 + k * CLG_TS + 4);
-      acc[0] = fmaf(w, v0.x, acc[0]); acc[1] = fmaf(w, v0.y, acc[1]); acc[2] = fmaf(w, v0.z, acc[2]); acc[3] = fmaf(w, v0.w, acc[3]);
-      acc[4] = fmaf(w, v1.x, acc[4]); acc[5] = fmaf(w, v1.y, acc[5]); acc[6] = fmaf(w, v1.z, acc[6]); acc[7] = fmaf(w, v1.w, acc[7]);
-    }
-    const int half = j < a.size_z ? 0 : 1, e = j - half * a.size_z, ch = half ? a.ch2 : a.ch1;
-#pragma unroll
-    for (int s = 0; s < CLG_TS; ++s) {
-      const int b = b0 + s;
-      if (b >= a.B) continue;
-      if (a.grad_out) a.grad_out[(long long)b * nx + j] = acc[s];
-      if (a.score && ((a.upd_mask >> half) & 1)) {
-        float* p = a.score + ((long long)b * a.C + ch) * a.per_mod + e;
-        *p = *p - a.cl_s * acc[s];
-      }
-    }
-  }
+              for (int s = 0; s < CLG_TS; ++s) {
+                const int b = b0 + s;
+                if (b >= a.B) continue;
+                if (a.grad_out) a.grad_out[(long long)b * nx + j] = acc[s];
+                if (a.score && ((a.upd_mask >> half) & 1)) {
+                  float* p = a.score + ((long long)b * a.C + ch) * a.per_mod + e;
+                  *p = *p - a.cl_s * acc[s];
+                }
+              }
+            });
 }
 
 }  // namespace
 
-size_t clg_lds_bytes(int D0) { return sizeof(float) * CLG_TS * (size_t)(D0 + 2 * CLG_H1 + 2 * CLG_H2 + CLG_TE); }
+size_t clg_lds_bytes(int D0) { return sizeof(float) * ((size_t)CLG_TS * (size_t)(D0 + 2 * CLG_H1 + 2 * CLG_H2 + CLG_TE) + CLG_PART); }
 
 // once per device, outside any stream capture (the fused guided loop calls it before it captures its step)
 void clg_prepare() { ensure_dynamic_lds(reinterpret_cast<const void*>(clg_kernel), 160 * 1024); }
