@@ -33,6 +33,35 @@ __device__ __forceinline__ float sbm_erf(float x) {
 #endif
 }
 
+// The same function on a PAIR of values with packed fp32 instructions (v_pk_fma_f32 / v_pk_mul_f32: two IEEE operations per issue slot,
+// lane for lane the operations of sbm_erf, hence bit-identical results): the GELU epilogues are VALU-issue-bound (a wave64 instruction
+// takes four cycles and two waves share a SIMD), so halving the polynomial's instruction count is worth more than its latency.
+typedef float sbm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ sbm_f32x2 sbm_fma2(sbm_f32x2 a, sbm_f32x2 b, float c) { return __builtin_elementwise_fma(a, b, (sbm_f32x2){c, c}); }
+__device__ __forceinline__ sbm_f32x2 sbm_erf2(sbm_f32x2 x) {
+#ifdef SBM_EXACT_ERF
+  return (sbm_f32x2){erff(x.x), erff(x.y)};
+#else
+  const sbm_f32x2 t = __builtin_elementwise_abs(x), s = x * x;
+  sbm_f32x2 p = {-0.0006008737254887819f, -0.0006008737254887819f};
+  p = sbm_fma2(p, s, 0.004997011739760637f); p = sbm_fma2(p, s, -0.026769496500492096f); p = sbm_fma2(p, s, 0.11281904578208923f);
+  p = sbm_fma2(p, s, -0.3761250376701355f); p = sbm_fma2(p, s, 0.12837915122509003f);
+  const sbm_f32x2 small = __builtin_elementwise_fma(p, x, x);
+  const sbm_f32x2 tc = __builtin_elementwise_min(t, (sbm_f32x2){4.0f, 4.0f});
+  sbm_f32x2 q = {1.6357038475689478e-05f, 1.6357038475689478e-05f};
+  q = sbm_fma2(q, tc, -0.0003699551452882588f); q = sbm_fma2(q, tc, 0.0038104963023215532f); q = sbm_fma2(q, tc, -0.02405124343931675f);
+  q = sbm_fma2(q, tc, 0.1064765453338623f); q = sbm_fma2(q, tc, 0.6350749731063843f); q = sbm_fma2(q, tc, 1.1286484003067017f);
+  const sbm_f32x2 a = -(q * tc) * 1.4426950408889634f;
+  const float e0 = __builtin_amdgcn_exp2f(a.x), e1 = __builtin_amdgcn_exp2f(a.y);
+  sbm_f32x2 r;
+  r.x = t.x < 0.921875f ? small.x : copysignf(1.0f - e0, x.x);
+  r.y = t.y < 0.921875f ? small.y : copysignf(1.0f - e1, x.y);
+  return r;
+#endif
+}
+// GELU(erf) of a pair: 0.5 v (1 + erf(v / sqrt 2)), the operation order of the scalar form
+__device__ __forceinline__ sbm_f32x2 sbm_gelu2(sbm_f32x2 v) { return 0.5f * v * (1.0f + sbm_erf2(v * 0.70710678118654752440f)); }
+
 // seg_gemm kernel arguments: a small by-value part used inside the K loop, and the rest in device memory.
 struct GemmCold {
   const float* bias;          // [Npad] (+ p * bias_pix_stride) or null

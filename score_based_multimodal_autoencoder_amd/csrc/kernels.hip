@@ -470,7 +470,12 @@ __global__ __launch_bounds__(256) void seg_gemm(const GemmHot g) {
             v.x += gb.x - mrs * gs.x; v.y += gb.y - mrs * gs.y; v.z += gb.z - mrs * gs.z; v.w += gb.w - mrs * gs.w;
           }
           if (c.R) { v.x += rv[t].x; v.y += rv[t].y; v.z += rv[t].z; v.w += rv[t].w; }
-          v.x = act_apply(c.act, v.x); v.y = act_apply(c.act, v.y); v.z = act_apply(c.act, v.z); v.w = act_apply(c.act, v.w);
+          if (c.act == ACT_GELU) {                     // packed pair form: half the VALU issue slots, bit-identical (device.h: sbm_gelu2)
+            const sbm_f32x2 g0 = sbm_gelu2((sbm_f32x2){v.x, v.y}), g1 = sbm_gelu2((sbm_f32x2){v.z, v.w});
+            v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;
+          } else if (c.act != ACT_NONE) {
+            v.x = act_apply(c.act, v.x); v.y = act_apply(c.act, v.y); v.z = act_apply(c.act, v.z); v.w = act_apply(c.act, v.w);
+          }
           *reinterpret_cast<float4*>(g.out + ((long long)p * g.B + bb) * c.ldo + n) = v;
           s = (v.x + v.y) + (v.z + v.w); q = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }

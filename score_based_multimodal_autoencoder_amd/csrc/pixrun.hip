@@ -366,34 +366,37 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         // audit in tests/test_host_api.py counts v_accvgpr instructions).  Task = (channel, output row py): 8 outputs from up to 7 rows.
         for (int i = tid; i < (49 * C) >> 2; i += PNT) *reinterpret_cast<float4*>(scr + 4 * i) = *reinterpret_cast<const float4*>(dw_w + 4 * i);
         __syncthreads();
-        for (int task = tid; task < C * 8; task += PNT) {
-          const int c = task % C, py = task / C;
-          float acc[8];
-          const float bi = dw_bias[c] + (cond ? cond[c] : 0.f);
+        // a thread owns TWO neighbouring channels of an output row: inputs and weights are float2, every tap is one v_pk_fma_f32 (this
+        // op is VALU-issue-bound: 392 FMAs per channel and row)
+        for (int task = tid; task < (C >> 1) * 8; task += PNT) {
+          const int c = (task % (C >> 1)) * 2, py = task / (C >> 1);
+          sbm_f32x2 acc[8];
+          sbm_f32x2 bi = *reinterpret_cast<const sbm_f32x2*>(dw_bias + c);
+          if (cond) bi += *reinterpret_cast<const sbm_f32x2*>(cond + c);
 #pragma unroll
-          for (int px = 0; px < 8; ++px) acc[px] = 0.f;
-#pragma unroll
+          for (int px = 0; px < 8; ++px) acc[px] = (sbm_f32x2){0.f, 0.f};
+#pragma unroll 1                                           // one window row at a time: unrolled, the seven rows' operands push the kernel past 128 VGPRs (AGPR spills)
           for (int ky = 0; ky < 7; ++ky) {
             const int qy = py + ky - 3;
             const bool in = qy >= 0 && qy < 8;
             const int qyc = in ? qy : 0;
-            float xr[8], wr[7];
+            sbm_f32x2 xr[8], wr[7];
 #pragma unroll
-            for (int qx = 0; qx < 8; ++qx) { const float v = lds[in_lds + pix_at2(c, qyc * 8 + qx, in_sub)]; xr[qx] = in ? v : 0.f; }
+            for (int qx = 0; qx < 8; ++qx) { const sbm_f32x2 v = *reinterpret_cast<const sbm_f32x2*>(lds + in_lds + pix_at2(c, qyc * 8 + qx, in_sub)); xr[qx] = in ? v : (sbm_f32x2){0.f, 0.f}; }
 #pragma unroll
-            for (int kx = 0; kx < 7; ++kx) wr[kx] = scr[(ky * 7 + kx) * C + c];
+            for (int kx = 0; kx < 7; ++kx) wr[kx] = *reinterpret_cast<const sbm_f32x2*>(scr + (ky * 7 + kx) * C + c);
 #pragma unroll
             for (int px = 0; px < 8; ++px)
 #pragma unroll
-              for (int kx = 0; kx < 7; ++kx) { const int qx = px + kx - 3; if (qx >= 0 && qx < 8) acc[px] = fmaf(xr[qx], wr[kx], acc[px]); }
+              for (int kx = 0; kx < 7; ++kx) { const int qx = px + kx - 3; if (qx >= 0 && qx < 8) acc[px] = __builtin_elementwise_fma(xr[qx], wr[kx], acc[px]); }
           }
 #pragma unroll
           for (int px = 0; px < 8; ++px) {
             const int p = py * 8 + px;
-            const float v = acc[px] + bi;
-            lds[out_lds + pix_at2(c, p, out_sub)] = v;
-            if (dw_out) dw_out[((long long)p * B + b) * ldo + c] = v;
-            s += v; qq += v * v;
+            const sbm_f32x2 v = acc[px] + bi;
+            *reinterpret_cast<sbm_f32x2*>(lds + out_lds + pix_at2(c, p, out_sub)) = v;
+            if (dw_out) *reinterpret_cast<sbm_f32x2*>(dw_out + ((long long)p * B + b) * ldo + c) = v;
+            s += v.x; s += v.y; qq += v.x * v.x; qq += v.y * v.y;
           }
         }
       } else {
@@ -602,8 +605,15 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             if (gn) t = t * rstd + (eg[j] - (mean * rstd) * es[j]);
             t += eb[j];
             if (res_lds >= 0) t += *reinterpret_cast<const f32x4p*>(lds + res_lds + pix_at2(col, P_out > 16 ? row : sbyte(res_row, row & 15), res_sub));
+            if (act == ACT_GELU) {                        // the one activation of the ConvNeXt blocks: packed, the switch outside the element loop
+              const sbm_f32x2 g0 = sbm_gelu2((sbm_f32x2){t[0], t[1]}), g1 = sbm_gelu2((sbm_f32x2){t[2], t[3]});
+              o[0] = g0.x; o[1] = g0.y; o[2] = g1.x; o[3] = g1.y;
+            } else if (act == ACT_NONE) {
+              o = t;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pix_act(act, t[e]);
+              for (int e = 0; e < 4; ++e) o[e] = pix_act(act, t[e]);
+            }
             if (out_lds >= 0) *reinterpret_cast<f32x4p*>(lds + out_lds + pix_at2(col, row, out_sub)) = o;
             if (out_g) *reinterpret_cast<f32x4p*>(out_g + ((long long)row * B + b) * ldo + col) = o;
             sacc += o[0] + o[1] + o[2] + o[3]; qacc += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
