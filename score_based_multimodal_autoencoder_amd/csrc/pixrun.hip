@@ -307,7 +307,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     return q;
   };
   // request the epilogue operands (bias, folded-GroupNorm S and B1) of a pass into a[104 .. 127]
-  auto request_epilogue_operands = [&](const PixItem* it) {
+  auto request_epilogue_operands = [&](const PixItem* it) -> Quads {
     const Quads q = quads_of(it);
     const int npad = ldc(&it->Npad), rst = ldc(&it->rowstride);
     const float* bias = ldc(&it->bias); const float* gs = ldc(&it->gn_s); const float* gb = ldc(&it->gn_b1);
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       const float* pb = bias + colc; const float* ps = gs + (long long)q.row[j] * rst + colc; const float* pg = gb + (long long)q.row[j] * rst + colc;
       if (j == 0) PIX_ELOAD(pb, ps, pg, 104, 107, 108, 111, 112, 115); else PIX_ELOAD(pb, ps, pg, 116, 119, 120, 123, 124, 127);
     }
+    return q;                                             // the pass's own epilogue reuses the mapping (the index arithmetic is VALU time)
   };
   int ci = 0;
   const PixItem* pc = items;
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     const float* base_ = frag + e.w_off;
     PIX_LOAD_SLOT(r, base_, off_c);
   }
-  request_epilogue_operands(pc);
+  Quads q_cur = request_epilogue_operands(pc);
   for (int k = 0; k < count; ++k) {
     const PixOpD& op = ops[k];
     const int kind = ldc(&op.kind);
@@ -584,8 +585,8 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         PIX_EREAD4(eb[0], 104, 105, 106, 107); PIX_EREAD4(es[0], 108, 109, 110, 111); PIX_EREAD4(eg[0], 112, 113, 114, 115);
         PIX_EREAD4(eb[1], 116, 117, 118, 119); PIX_EREAD4(es[1], 120, 121, 122, 123); PIX_EREAD4(eg[1], 124, 125, 126, 127);
-        request_epilogue_operands(pn);                     // a[104 .. 127] are free again: the next pass's operands fly under this epilogue and its K loop
-        const Quads q = quads_of(pc);
+        const Quads q = q_cur;
+        q_cur = request_epilogue_operands(pn);             // a[104 .. 127] are free again: the next pass's operands fly under this epilogue and its K loop
         const int gw = small ? 64 : 32, gshift = ldc(&pc->gshift), ushift = gshift + ldc(&pc->rshift), ksplit = 1 << ldc(&pc->kshift), grp0 = ldc(&pc->grp0);
         const int out_sub = ldc(&pc->out_sub), res_sub = ldc(&pc->res_sub), P_out = ldc(&pc->P_out);
         const int nstore = ldc(&pc->nstore), act = ldc(&pc->act), out_lds = ldc(&pc->out_lds), res_lds = ldc(&pc->res_lds), ldo = ldc(&pc->ldo);
