@@ -255,6 +255,19 @@ def extra_measurements(cfg, score, decs, sde, x0, zc, device):
         except Exception as exc:
             out["annealed_langevin"] = {"error": str(exc)[:200]}
         try:
+            # MLP-score Langevin chain (fid_upd10.calc_poly_uncond :311-339): LSMPoly64_sm over the joint latent, 200 iterations
+            from score_based_multimodal_autoencoder_amd.lat_sm2_model import LSMPoly64_sm
+            mlp = synth.fill_module_(LSMPoly64_sm(n_mod=W["n_mod"], size_z=W["hw"] * W["hw"]).eval()).to(device)
+            zm = x0.reshape(B, W["n_mod"], -1)
+            LG.mlp_langevin(mlp, zm, n_comp=200, seed=15)
+            t_dev, _ = wall(lambda: LG.mlp_langevin(mlp, zm, n_comp=200, seed=15))
+            t_py, _ = wall(lambda: LG.mlp_langevin(mlp, zm, n_comp=200, seed=15, fused=False))
+            out["mlp_langevin"] = {"score_calls_per_s": 200 / t_dev, "ms_per_score_call": 1e3 * t_dev / 200, "python_loop_ms_per_score_call": 1e3 * t_py / 200,
+                                   "note": "LSMPoly64_sm + fixed-step update, 200 iterations; device-resident loop (sbm_langevin_run) vs the Python loop over the same kernels"}
+            mlp.release_engines()
+        except Exception as exc:
+            out["mlp_langevin"] = {"error": str(exc)[:200]}
+        try:
             # classifier-guided conditional loop (sde_helper2.py:283-312, 65-94): modality 0 observed, one ClwithTime2 per (given, predicted) pair
             from score_based_multimodal_autoencoder_amd.lat_sm2_model import ClwithTime2
             mods = "".join(str(i) for i in range(W["n_mod"]))

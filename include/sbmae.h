@@ -180,16 +180,19 @@ int sbm_clg_guide(sbm_model* m, const float* x, const float* t, int ch1, int ch2
 int sbm_langevin_fixed_step(const float* x, const float* score, const float* noise, float* x_out, float a, float b, float score_div,
                             unsigned mod_mask, int B, int n_mod, int per_mod, uint64_t seed, uint64_t sample_offset, int step, int draw, void* stream);
 
-/* Device-resident annealed-Langevin loop over a time-conditioned score net (SBM_UNET / SBM_UNET_OA) == fid_upd10.gen_ae :84-99 and
- * eval_lat_celeba_hq_all.evaluate :258-275 as ONE call: for k in [0, n_iter):
- *   score = net(z, times[k]);   z[:, m] += a[k][m] * (score[:, m] / score_div[k]) + b[k][m] * noise_k[:, m]   for bit m of mod_mask set.
- * times (n_iter,) and coef (n_iter, 2*n_mod + 1) = rows [a_0 .. a_{n_mod-1} | b_0 .. b_{n_mod-1} | score_div] are DEVICE arrays; the
- * iteration index lives in device memory, the net's time path is tabulated once for all iterations, and one captured hipGraph
- * {score net, update, advance} is replayed n_iter times (use_graph != 0).  noise (n_iter, B, n_mod*per_mod) or NULL: in-kernel Philox
- * keyed (seed, sample_offset + row, step = k, draw = 0) -- the stream sbm_langevin_fixed_step(step = k) uses, so the loop reproduces the
- * per-iteration calls bit for bit.  z_inout (B, n_mod, per_mod) is updated in place.  elapsed_ms (optional): loop time by HIP events. */
+/* Device-resident fixed-step Langevin loops as ONE call: the annealed chain over a time-conditioned score net (SBM_UNET / SBM_UNET_OA;
+ * fid_upd10.gen_ae :84-99, eval_lat_celeba_hq_all.evaluate :258-275) and the MLP-score chain (SBM_MLP; fid_upd10.calc_poly_uncond
+ * :311-339).  For k in [0, n_iter):
+ *   score = net(z [, times[k]]);   z[:, m] += a[k][m] * (score[:, m] / score_div[k]) + b[k][m] * noise_k[:, m]   for bit m of mod_mask set.
+ * times (n_iter,; NULL for a net without time input) and coef (n_iter, 2*n_mod + 1) = rows [a_0 .. a_{n_mod-1} | b_0 .. b_{n_mod-1} |
+ * score_div] are DEVICE arrays; the iteration index lives in device memory, a net's time path is tabulated once for all iterations, and
+ * one captured hipGraph {score net, update, advance} is replayed n_iter times (use_graph != 0).  tail: NULL, or a HOST row of the same
+ * layout applied once more with the LAST iteration's score (calc_poly_uncond's closing step, :336-339; Philox draw 1 of that iteration).
+ * noise (n_iter [+ 1 with tail], B, n_mod*per_mod) or NULL: in-kernel Philox keyed (seed, sample_offset + row, step = k, draw = 0) --
+ * the stream sbm_langevin_fixed_step(step = k) uses, so the loop reproduces the per-iteration calls bit for bit.  z_inout
+ * (B, n_mod, per_mod) is updated in place.  elapsed_ms (optional): loop time by HIP events. */
 int sbm_langevin_run(sbm_model* m, const float* times, const float* coef, unsigned mod_mask, int n_mod, int n_iter, const float* noise,
-                     float* z_inout, uint64_t seed, uint64_t sample_offset, int use_graph, float* elapsed_ms, void* stream);
+                     float* z_inout, uint64_t seed, uint64_t sample_offset, int use_graph, const float* tail, float* elapsed_ms, void* stream);
 
 /* Conditional loop: re-noise the OBSERVED modalities at time t, x_out[:, m] = mean(t)*z_obs[:, m] + std(t)*z_obs[:, m]
  * for bit m of obs_mask set (the reference multiplies std by z itself, train_poly_unet_cont.py:363-364), x[:, m] otherwise;

@@ -108,7 +108,7 @@ def lib():
         L.sbm_model_gemm_flops.argtypes = [vp, ctypes.POINTER(dbl)]
         L.sbm_em_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
         L.sbm_langevin_step.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
-        L.sbm_langevin_run.argtypes = [vp, vp, vp, ctypes.c_uint, i, i, vp, vp, u64, u64, i, ctypes.POINTER(ctypes.c_float), vp]
+        L.sbm_langevin_run.argtypes = [vp, vp, vp, ctypes.c_uint, i, i, vp, vp, u64, u64, i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), vp]
         L.sbm_langevin_norms.argtypes = [vp, vp, vp, vp, i, i, u64, u64, i, i, vp]
         L.sbm_langevin_update.argtypes = [ctypes.POINTER(SdeCfg), vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_long, i, i, u64, u64, i, i, vp]
         L.sbm_clg_forward.argtypes = [vp, vp, vp, i, i, vp, i, vp]

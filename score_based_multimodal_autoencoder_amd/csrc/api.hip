@@ -246,7 +246,7 @@ static int model_create_impl(int kind, const int* cfg, int batch, int in_pitch, 
   std::vector<float> host_params;
   host_params.swap(m->plan.params);                   // the plan no longer needs its host copy; the pixel kernel's packer (below) still does
   for (int i = 0; i + 1 < (int)m->plan.ops.size(); ++i) if (qkv_linattn_fusable(m->plan, i)) m->plan.ops[i].fuse_next = 1;
-  if (kind == SBM_UNET || kind == SBM_UNET_OA) {
+  if (kind == SBM_UNET || kind == SBM_UNET_OA || kind == SBM_MLP) {
     if ((e = hipMalloc(&m->d_counter, 64)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(counter)", e); }
     (void)hipMemset(m->d_counter, 0, 64);
     m->dp.ctl = reinterpret_cast<const StepCtl*>(m->d_counter);
@@ -343,7 +343,7 @@ static int model_create_impl(int kind, const int* cfg, int batch, int in_pitch, 
       m->dp.chain_ctl.abort_host = dev_view;
     }
   }
-  if (kind == SBM_UNET || kind == SBM_UNET_OA) {
+  if (kind == SBM_UNET || kind == SBM_UNET_OA || kind == SBM_MLP) {
     const size_t sbytes = (size_t)batch * m->plan.out_C * m->plan.out_H * m->plan.out_W * sizeof(float);
     if ((e = hipMalloc(&m->d_score, sbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(score)", e); }
     if ((e = hipMalloc(&m->d_norms, (size_t)batch * 2 * sizeof(float))) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(norms)", e); }
@@ -984,18 +984,22 @@ int sbm_guided_cond_sampler_run(sbm_model* m, const sbm_sde_cfg* sde, const sbm_
   return sampler_run_impl(m, sde, cfg, cond, z_obs, timesteps, alphas, noise, x_inout, x_mean_out, first_step, n_run, elapsed_ms, stream, &guide);
 }
 
-// Device-resident annealed-Langevin loop (fid_upd10.gen_ae :84-99, eval_lat_celeba_hq_all.evaluate :258-275): n_iter iterations of
-//   score = net(z, times[k]);  z[:, m] += a[k][m] * score[:, m] / score_div[k] + b[k][m] * N   (m in mod_mask)
-// with the iteration index in device memory, the time path tabulated once for all iterations, and ONE captured graph
-// {score net, update, advance} replayed n_iter times.  coef rows: [a_0..a_{n_mod-1} | b_0..b_{n_mod-1} | score_div].
+// Device-resident fixed-step Langevin loops: annealed Langevin over a time-conditioned score net (fid_upd10.gen_ae :84-99,
+// eval_lat_celeba_hq_all.evaluate :258-275) and the MLP-score chain (fid_upd10.calc_poly_uncond :311-339).  n_iter iterations of
+//   score = net(z [, times[k]]);  z[:, m] += a[k][m] * score[:, m] / score_div[k] + b[k][m] * N   (m in mod_mask)
+// with the iteration index in device memory, the time path (if the net has one) tabulated once for all iterations, and ONE captured
+// graph {score net, update, advance} replayed n_iter times.  coef rows: [a_0..a_{n_mod-1} | b_0..b_{n_mod-1} | score_div].
+// tail (host, optional): one more update with the LAST score and its own row -- calc_poly_uncond's closing step (:336-339).
 int sbm_langevin_run(sbm_model* m, const float* times, const float* coef, unsigned mod_mask, int n_mod, int n_iter, const float* noise, float* z_inout,
-                     uint64_t seed, uint64_t sample_offset, int use_graph, float* elapsed_ms, void* stream) {
-  if (!m || (m->kind != SBM_UNET && m->kind != SBM_UNET_OA) || !times || !coef || !z_inout || n_iter < 0 || n_mod <= 0 || n_mod > 32) return fail("sbm_langevin_run: bad arguments");
+                     uint64_t seed, uint64_t sample_offset, int use_graph, const float* tail, float* elapsed_ms, void* stream) {
+  if (!m || (m->kind != SBM_UNET && m->kind != SBM_UNET_OA && m->kind != SBM_MLP) || !coef || !z_inout || n_iter < 0 || n_mod <= 0 || n_mod > 32) return fail("sbm_langevin_run: bad arguments");
   const int B = m->plan.B, CHW = m->plan.out_C * m->plan.out_H * m->plan.out_W;
-  if (m->plan.in_C != m->plan.out_C) return fail("sbm_langevin_run: score net must map the state onto itself");
+  if (m->plan.in_C != m->plan.out_C || m->plan.in_H != m->plan.out_H || m->plan.in_W != m->plan.out_W) return fail("sbm_langevin_run: score net must map the state onto itself");
   if (CHW % n_mod || (CHW / n_mod) % 4) return fail("sbm_langevin_run: the state must split into n_mod modalities of a multiple of 4 floats");
-  if (!m->plan.needs_time || m->plan.cond_off < 0 || m->plan.time_off < 0) return fail("sbm_langevin_run: the score net has no tabulated time path");
+  const bool timed = m->plan.needs_time != 0;
+  if (timed && (!times || m->plan.cond_off < 0 || m->plan.time_off < 0)) return fail("sbm_langevin_run: a time-conditioned score net needs the times array and a tabulated time path");
   if (m->plan.aux_off >= 0 && !m->aux_persistent) return fail("sbm_langevin_run: the score net was built with z conditioning; call sbm_model_set_aux first");
+  if (tail && n_iter == 0) return fail("sbm_langevin_run: a closing step needs at least one iteration (it reuses the last score)");
   m->dp.aux = m->aux_persistent;
   hipStream_t caller = (hipStream_t)stream, st = m->own;
   if (int rc = chain_prior_abort(m, st, "sbm_langevin_run")) return rc;
@@ -1004,7 +1008,7 @@ int sbm_langevin_run(sbm_model* m, const float* times, const float* coef, unsign
   launch_set_counter(m->d_counter, 0, st);
   TableModeGuard guard{m, st};
   GraphGuard gg{st};
-  if (n_iter > 0) {
+  if (timed && n_iter > 0) {
     if (int rc = build_time_table(m, times, n_iter, z_inout, st, "sbm_langevin_run")) return rc;
     guard.armed = true;
   }
@@ -1012,7 +1016,7 @@ int sbm_langevin_run(sbm_model* m, const float* times, const float* coef, unsign
   a.x = z_inout; a.x_out = z_inout; a.score = m->d_score; a.noise = noise; a.noise_step_stride = (long long)B * CHW; a.step_counter = m->d_counter;
   a.B = B; a.CHW = CHW; a.seed = seed; a.sample_offset = sample_offset; a.draw = 0;
   auto enqueue = [&]() -> const char* {
-    if (const char* e = run_plan(m->dp, z_inout, m->d_ws + m->plan.time_off, m->d_score, st, 1)) return e;
+    if (const char* e = timed ? run_plan(m->dp, z_inout, m->d_ws + m->plan.time_off, m->d_score, st, 1) : run_plan(m->dp, z_inout, nullptr, m->d_score, st, 0)) return e;
     launch_axpy_noise_tab(a, coef, mod_mask, n_mod, CHW / n_mod, st);              // element-wise: in place is safe
     launch_advance(m->d_counter, st);
     return nullptr;
@@ -1029,6 +1033,13 @@ int sbm_langevin_run(sbm_model* m, const float* times, const float* coef, unsign
   for (int i = 0; i < n_iter; ++i) {
     if (gg.exec) { hipError_t le = hipGraphLaunch(gg.exec, st); if (le != hipSuccess) return fail_hip("hipGraphLaunch", le); }
     else if (const char* e = enqueue()) return fail(std::string("sbm_langevin_run: ") + e);
+  }
+  if (tail) {                              // the closing update: the last iteration's score once more, Philox draw 1 of that iteration
+    StepArgs t = a;
+    t.step_counter = nullptr; t.step_base = n_iter - 1; t.draw = 1;
+    if (noise) { t.noise = noise + (long long)n_iter * B * CHW; t.noise_step_stride = 0; }
+    for (int md = 0; md < n_mod; ++md)
+      if ((mod_mask >> md) & 1u) launch_axpy_noise(t, tail[md], tail[n_mod + md], tail[2 * n_mod], 1u << md, CHW / n_mod, st);
   }
   if (elapsed_ms) HIPCHK(hipEventRecord(m->ev_t1, st));
   if (guard.armed) { HIPCHK(hipMemsetAsync(reinterpret_cast<char*>(m->d_counter) + 4, 0, 4, st)); guard.armed = false; }

@@ -122,7 +122,7 @@ def annealed_langevin(score_model, z, sigmas=None, er=None, c=None, iter_num=Non
                 raise ValueError(f"noise needs {n_iter} draws")
         ms = ctypes.c_float(0.0)
         _lib.check(_lib.lib().sbm_langevin_run(eng.h, tdev.data_ptr(), coef.data_ptr(), mask, n_mod, n_iter,
-                                               noise.data_ptr() if noise is not None else None, z.data_ptr(), seed, int(sample_offset), 1,
+                                               noise.data_ptr() if noise is not None else None, z.data_ptr(), seed, int(sample_offset), 1, None,
                                                ctypes.byref(ms) if return_timing else None, _lib.stream_ptr()))
         return (z, ms.value) if return_timing else z
     single = len(groups) == 1
@@ -151,16 +151,46 @@ def annealed_langevin(score_model, z, sigmas=None, er=None, c=None, iter_num=Non
 
 
 def mlp_langevin(score_model, z, n_comp=50, lr1=0.03, lr2=0.001, schedule=False, predicted=None, noise=None, *, seed=None,
-                 sample_offset=0):
+                 sample_offset=0, fused=None, return_timing=False):
     """Fixed-step Langevin with the MLP score (fid_upd10.calc_poly_uncond :311-339).
 
     z (B, n_mod, size_z); score_model(z.view(B, -1)) -> (B, n_mod*size_z).  With `schedule` the score step is
     lr1*(i+1)/n_comp and the last
-    iteration applies a second update of size 1 with the same score (fid_upd10.py:336-339); noise then has n_comp+1 draws."""
+    iteration applies a second update of size 1 with the same score (fid_upd10.py:336-339); noise then has n_comp+1 draws.
+    fused: None (default) = the device-resident loop (sbm_langevin_run: iteration counter on the device, one captured graph per
+    iteration) when `score_model` is this package's `LSMPoly64_sm`, the Python loop for any other callable; the two agree bit for bit."""
+    from .lat_sm2_model import LSMPoly64_sm
     z = as_f32_cuda(z, "z").clone()
-    B = z.shape[0]
+    B, n_mod = z.shape[0], z.shape[1]
     seed = fresh_seed(seed)
+    if fused is None:
+        fused = isinstance(score_model, LSMPoly64_sm) and not score_model.training
+    if fused and n_comp > 0:
+        rows = np.zeros((n_comp, 2 * n_mod + 1), np.float32)
+        for i in range(n_comp):
+            rows[i, :n_mod] = np.float32(lr1 * ((i + 1) / n_comp) if schedule else lr1)
+        rows[:, n_mod:2 * n_mod] = np.float32(lr2)
+        rows[:, 2 * n_mod] = 1.0
+        tail = None
+        if schedule:
+            tl = np.zeros(2 * n_mod + 1, np.float32)
+            tl[:n_mod] = np.float32(1 * (n_comp / n_comp)); tl[n_mod:2 * n_mod] = np.float32(lr2); tl[2 * n_mod] = 1.0
+            tail = (ctypes.c_float * tl.size)(*tl.tolist())
+        if noise is not None:
+            noise = as_f32_cuda(noise, "noise")
+            if noise.shape[0] < n_comp + (1 if schedule else 0):
+                raise ValueError(f"noise needs {n_comp + (1 if schedule else 0)} draws")
+        eng = score_model._engine_for(B)
+        coef = torch.from_numpy(rows).to(z.device)
+        ms = ctypes.c_float(0.0)
+        _lib.check(_lib.lib().sbm_langevin_run(eng.h, None, coef.data_ptr(), _mask(n_mod, predicted), n_mod, n_comp,
+                                               noise.data_ptr() if noise is not None else None, z.data_ptr(), seed, int(sample_offset), 1, tail,
+                                               ctypes.byref(ms) if return_timing else None, _lib.stream_ptr()))
+        return (z, ms.value) if return_timing else z
     buf = torch.empty_like(z)
+    if return_timing:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     with torch.no_grad():
         for i in range(n_comp):
             score = score_model(z.view(B, -1))
@@ -172,4 +202,7 @@ def mlp_langevin(score_model, z, n_comp=50, lr1=0.03, lr2=0.001, schedule=False,
                 langevin_fixed_step(z, score, 1 * ((i + 1) / n_comp), lr2, predicted, None if noise is None else noise[n_comp],
                                     seed=seed, sample_offset=sample_offset, step=i, draw=1, out=buf)
                 z, buf = buf, z
+    if return_timing:
+        ev1.record(); ev1.synchronize()
+        return z, ev0.elapsed_time(ev1)
     return z

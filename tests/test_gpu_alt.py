@@ -168,6 +168,27 @@ def test_annealed_langevin_device_loop_equals_python_loop_bit_for_bit(pkg):
     assert torch.equal(z1, a) and ms > 0
 
 
+@pytest.mark.parametrize("schedule", [False, True])
+def test_mlp_langevin_device_loop_equals_python_loop_bit_for_bit(pkg, schedule):
+    """The MLP-score chain (fid_upd10.calc_poly_uncond :311-339) as one device-resident call (sbm_langevin_run on an SBM_MLP handle, with
+    the schedule's closing step on the last score) against the Python loop over the same kernels: bit for bit, Philox and injected noise."""
+    lang = pkg["lang"]
+    from score_based_multimodal_autoencoder_amd.lat_sm2_model import LSMPoly64_sm
+    mlp = pkg["synth"].fill_module_(LSMPoly64_sm(n_mod=3, size_z=64).eval()).cuda()
+    z0 = torch.randn(6, 3, 64, device="cuda")
+    kw = dict(n_comp=9, lr1=0.03, lr2=0.001, schedule=schedule, predicted=[0, 2])
+    a = lang.mlp_langevin(mlp, z0, seed=21, fused=True, **kw)
+    b = lang.mlp_langevin(mlp, z0, seed=21, fused=False, **kw)
+    assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a[:, 1], z0[:, 1]) and not torch.equal(a[:, 0], z0[:, 0])
+    assert torch.equal(lang.mlp_langevin(mlp, z0, seed=21, **kw), a)                  # default: the device loop for this package's MLP
+    nz = torch.randn(10, 6, 3, 64, device="cuda")
+    a2 = lang.mlp_langevin(mlp, z0, noise=nz, fused=True, **kw)
+    b2 = lang.mlp_langevin(mlp, z0, noise=nz, fused=False, **kw)
+    assert torch.equal(a2, b2) and not torch.equal(a2, a)
+    y = mlp(z0.view(6, -1))
+    assert torch.isfinite(y).all()                                                      # the handle serves ordinary forwards afterwards
+
+
 @pytest.mark.parametrize("tag,noise_obs,pc", [("nobs1_pc1", True, True), ("nobs0_pc0", False, False)])
 def test_conditional_loop_matches_evaluate(pkg, golden, tag, noise_obs, pc):
     g = golden("conditional.npz")
