@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Config 2 at full size (B = 256, 1000 reverse-SDE steps): how far do the samples move when (a) the batch is cut into two shards keyed by
+their global sample offset, (b) other kernels carry the low-resolution levels (SBM_CHAIN_PIX = 0 / 16 / 64)?  Prints the differences
+relative to max|x| -- the numbers behind the 1e-5 bounds of tests/test_gpu_parity.py::test_full_size_sampling_run_is_path_and_shard_independent."""
 import os, sys, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from score_based_multimodal_autoencoder_amd import _lib, synth
