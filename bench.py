@@ -47,6 +47,10 @@ WORK = {
             B=64, n_mod=3, hw=16, beta=(0.1, 20.0), score_flop=9_349_614_848, dec_flop=8_277_000_000 + 3_064_000_000 + 1_600_000),
     5: dict(name="CelebAMaskHQ conditional, 1000-step reverse SDE (VPSDE EM predictor, pc=False), batch 64 per GPU, UNetModel(3,128,3,2,(),0.1,(1,2,4,8),use_z,z_dim=512)+z_cond on 16x16 latents + the CelebA decoders",
             B=64, n_mod=3, hw=16, beta=(0.1, 20.0), score_flop=5_467_734_016, dec_flop=8_277_000_000 + 3_064_000_000 + 1_600_000),
+    # the PolyMNIST recipe as shipped (train_poly.sh:17: 10 modalities -> Unet(128, ch=10), beta = (1, 5), --pc=1): not a BASELINE config, an
+    # extra workload; `--pc` turns its corrector on in the timed pass (order predictor -> corrector, train_poly_unet_cont.py:180-186)
+    10: dict(name="PolyMNIST 10-modality recipe (train_poly.sh:17), 1000-step reverse SDE (VPSDE beta=(1,5)), batch 256 per GPU, Unet(128,ch=10,(1,2,2,2)) + 10 ResVAE decoders -> 32x32 images",
+             B=256, n_mod=10, hw=8, beta=(1.0, 5.0), score_flop=605_100_000, dec_flop=10 * 243_662_848),
 }
 
 
@@ -111,6 +115,9 @@ def build_models(cfg, device):
     if cfg == 2:
         score = Unet(dim=64, channels=5, dim_mults=(1, 2, 2, 2))
         decs = [ResVAE(arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3) for _ in range(5)]
+    elif cfg == 10:
+        score = Unet(dim=128, channels=10, dim_mults=(1, 2, 2, 2))
+        decs = [ResVAE(arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3) for _ in range(10)]
     else:
         score = Unet(dim=256, channels=3, dim_mults=(1, 2, 2, 2, 2)) if cfg == 4 else \
             UNetModel(3, 128, 3, 2, (), 0.1, (1, 2, 4, 8), num_heads=1, use_z=True, z_dim=512)
@@ -120,12 +127,14 @@ def build_models(cfg, device):
     return score, decs
 
 
-def one_pass(cfg, score, decs, sde, x0, zc, seed, start, device, timing=False):
+def one_pass(cfg, score, decs, sde, x0, zc, seed, start, device, timing=False, pc=False):
     """prior -> N-step sampler -> decoders on this rank's rows [start, start + B)."""
     from score_based_multimodal_autoencoder_amd.sde_helper2 import uncond_sampler
     W = WORK[cfg]
     B = x0.shape[0]
     kw = {} if zc is None else {"z_cond": zc}
+    if pc:
+        kw.update(pc=True, order="pc" if cfg in (2, 10) else "cp")          # PolyMNIST: predictor -> corrector; CelebA evaluate(): corrector -> predictor (SURVEY D2)
     r = uncond_sampler((B, W["n_mod"], W["hw"], W["hw"]), score, device, sde, x0=x0, seed=seed, sample_offset=start, return_timing=timing, **kw)
     z, ms = (r if timing else (r, None))
     sz = W["hw"] * W["hw"]
@@ -154,6 +163,11 @@ def cpu_baseline(cfg, reps=3, n_steps=20):
             dsd = sd_of(arch.resvae_state_shapes("ResVAE", arch.POLY_ENC, arch.POLY_DEC, 32, 64, 3))
             fwd = lambda x, vt: TP.unet_forward(sd, x, vt, 64, 4)
             dec = lambda xm: [TP.poly_decoder(dsd, xm[:, i].reshape(B, 64), arch.POLY_DEC) for i in range(5)]
+        elif cfg == 10:
+            B = 64                                                   # bounded sample: 1/4 of the batch, scaled linearly
+            sd = sd_of(arch.unet_state_shapes(dim=128, channels=10, dim_mults=(1, 2, 2, 2)))
+            fwd = lambda x, vt: TP.unet_forward(sd, x, vt, 128, 4)
+            dec = None
         elif cfg == 4:
             B = 8                                                    # bounded sample: 1/8 of the batch, scaled linearly
             sd = sd_of(arch.unet_state_shapes(dim=256, channels=3, dim_mults=(1, 2, 2, 2, 2)))
@@ -168,7 +182,9 @@ def cpu_baseline(cfg, reps=3, n_steps=20):
             dec = None
         x = torch.from_numpy(synth.noise(0, 0, (B, W["n_mod"], W["hw"], W["hw"])))
         ts = torch.linspace(1.0, 1e-3, N_SDE)
-        if cfg != 2:
+        if cfg == 10:
+            n_steps, reps = 5, 3
+        elif cfg != 2:
             n_steps, reps = 3, 3
         log(f"cpu_baseline: {cores} threads ({out['cpu_model']}), {reps} x {n_steps} SDE steps at B={B}")
         fwd(x, torch.ones(B) * ts[0])                                                  # warm-up
@@ -315,28 +331,64 @@ def self_launch(n, argv):
     does not initialise it), so no process that has initialised a GPU is ever replaced or forked."""
     import socket
     import subprocess
+    import tempfile
+    import threading
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+        logs.append(None if r == 0 else tempfile.TemporaryFile())          # the other ranks' stdout + stderr are kept and shown if anything fails
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else logs[r],
+                                      stderr=None if r == 0 else subprocess.STDOUT))
+    # rank 0's pipe is drained by a thread while ALL children are polled: the first rank that fails (or the overall time limit) ends
+    # its siblings at once, so nobody sits in a rendezvous holding a GPU until the collective time-out
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("SBM_BENCH_TIMEOUT_S", "3000"))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]                     # every child, every round (no short-circuit)
+        if all(rc is not None for rc in rcs):
+            break
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad or time.monotonic() > deadline:
+            failed = f"rank {bad[0][0]} exited with {bad[0][1]}" if bad else "overall time limit reached"
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.monotonic() + 10
+            while any(p.poll() is None for p in procs) and time.monotonic() < t_kill:
+                time.sleep(0.1)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
-    bad = [rc for rc in rcs if rc != 0]
-    if bad:
-        print(f"bench.py: rank exit codes {rcs}", file=sys.stderr)
-    return max(abs(rc) for rc in rcs) if bad else 0
+    if failed or any(rcs):
+        print(f"bench.py: {failed or 'a rank failed'}; rank exit codes {rcs} (negative = killed by that signal)", file=sys.stderr)
+        for r in range(1, n):
+            logs[r].seek(0)
+            tail = logs[r].read().decode(errors="replace")[-2000:]
+            if tail.strip():
+                print(f"---- rank {r} output (tail) ----\n{tail}", file=sys.stderr)
+        return 1
+    return 0
 
 
 def dry_run(args):
     """The launcher / sharding / gather / max-over-ranks timing path with no GPU: gloo on the CPU, a toy sample function of the
     GLOBAL row indices.  Rank 0 prints one JSON line whose n_gpus is the world size the process group actually has."""
     from score_based_multimodal_autoencoder_amd import distributed as D
+    if os.environ.get("SBM_BENCH_DRY_FAIL_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(3)                               # the launcher's test: a rank that dies at start-up must take its siblings down
     rank, world = D.init_from_env("gloo") if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
     B = 8
 
@@ -372,7 +424,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 4, 5, 10), help="BASELINE config 2 / 4 / 5; 10 = the PolyMNIST 10-modality recipe of train_poly.sh (extra workload)")
+    ap.add_argument("--pc", action="store_true", help="predictor-corrector sampling in the timed pass (what the recipes run: train_poly.sh:17, train_cel.sh:8): two score evaluations per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--cpu-reps", type=int, default=3)
@@ -425,7 +478,7 @@ def main():
         # the gloo-tested helper IS the benched path: this rank's rows, then ONE all-gather (RCCL over xGMI) of the packed outputs
         def sample_fn(first, count):
             assert first == start and count == B
-            _, outs, _ = one_pass(cfg, score, decs, sde, x0, zc, seed, first, device)
+            _, outs, _ = one_pass(cfg, score, decs, sde, x0, zc, seed, first, device, pc=args.pc)
             return tuple(outs)
         return D.sample_sharded(sample_fn, world * B)
 
@@ -447,13 +500,15 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / elapsed
-        flop_per_sample = W["score_flop"] * N_SDE + W["dec_flop"]
+        flop_per_sample = W["score_flop"] * N_SDE * (2 if args.pc else 1) + W["dec_flop"]
         line = {
-            "metric": "samples/sec (1000-step reverse SDE, PolyMNIST 5-mod)" if cfg == 2 else f"samples/sec (1000-step reverse SDE, BASELINE config {cfg})",
+            "metric": "samples/sec (1000-step reverse SDE, PolyMNIST 5-mod)" if cfg == 2 else
+                      ("samples/sec (1000-step reverse SDE, PolyMNIST 10-mod recipe)" if cfg == 10 else f"samples/sec (1000-step reverse SDE, BASELINE config {cfg})"),
             "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": W["name"], "baseline_config": cfg, "global_batch": world * B, "sde_steps": N_SDE,
+            "config": {"workload": W["name"] + (" -- predictor-corrector (pc=True, n_steps=1, snr=0.16): two score evaluations per step" if args.pc else ""),
+                       "baseline_config": cfg if cfg != 10 else None, "global_batch": world * B, "sde_steps": N_SDE, "pc": bool(args.pc),
                        "parallelism": f"batch-shard x{world}, 1 all-gather"},
         }
         # ---- roofline of the dominant GEMM kernel, measured live with HIP events riding on each kernel's own dispatch ----
@@ -483,7 +538,7 @@ def main():
         # (separate FETCH_SIZE / WRITE_SIZE / SQ passes over eager forwards, tools/traffic_probe.py; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for gfx950; unit KB).  Null when the profile was taken with a different build.
         traffic = mfma_busy = None
-        tag = f"r03_c{cfg}"
+        tag = f"r04_c{cfg}"
         tj = committed_profile(f"{tag}_traffic.json")
         if tj:
             rows = [v for k, v in tj["kernels"].items() if dom in k]
@@ -497,7 +552,7 @@ def main():
             rows = [v for k, v in sj["kernels"].items() if dom in k and "mfma_busy_frac" in v]
             if rows:
                 mfma_busy = sum(r["mfma_busy_frac"] * r["GRBM_GUI_ACTIVE"] * r["launches"] for r in rows) / sum(r["GRBM_GUI_ACTIVE"] * r["launches"] for r in rows)
-        _, _, loop_ms = one_pass(cfg, score, decs, sde, x0, zc, 7, start, device, timing=True)
+        _, _, loop_ms = one_pass(cfg, score, decs, sde, x0, zc, 7, start, device, timing=True, pc=args.pc)
         fwd_ms = sum(v["ms"] for v in prof.values())
         line["roofline"] = {
             "bound": "mfma", "achieved": kern[dom]["achieved"], "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -24,6 +24,7 @@ def _bump_registration_epoch(*_args):
 
 torch.nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
 torch.nn.modules.module.register_module_buffer_registration_hook(_bump_registration_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_registration_epoch)      # model.block = other_block
 
 
 class ParamTreeModule(nn.Module):
@@ -71,10 +72,19 @@ class ParamTreeModule(nn.Module):
         registration hook bumps `_REG_EPOCH`: assigning a new `nn.Parameter`, `register_buffer`, `.to()` / `.half()` replacing
         tensors); in-place updates (`copy_`, optimizer steps, `load_state_dict`) and `.data =` swaps show up in the cheap per-tensor
         check that is still made on every call (~60 us)."""
-        if self.__dict__.get("_sbm_tensors_epoch") != _REG_EPOCH[0]:
-            self.__dict__["_sbm_tensors"] = list(self.parameters()) + list(self.buffers())
-            self.__dict__["_sbm_tensors_epoch"] = _REG_EPOCH[0]
-        return tuple((p.data_ptr(), p._version) for p in self.__dict__["_sbm_tensors"])
+        d = self.__dict__
+        if d.get("_sbm_tensors_epoch") == _REG_EPOCH[0]:
+            # writes that bypass registration (`mod._parameters[name] = t`: parametrize / functional_call-style swaps) bump no epoch:
+            # the cached list is checked against the dicts it was read from (identity of every entry, ~20 us for Unet(64))
+            for dct, vals in d["_sbm_dicts"]:
+                if len(dct) != len(vals) or any(a is not b for a, b in zip(dct.values(), vals)):
+                    d.pop("_sbm_tensors_epoch")
+                    break
+        if d.get("_sbm_tensors_epoch") != _REG_EPOCH[0]:
+            d["_sbm_tensors"] = list(self.parameters()) + list(self.buffers())
+            d["_sbm_dicts"] = [(dct, tuple(dct.values())) for m in self.modules() for dct in (m._parameters, m._buffers, m._modules) if dct]
+            d["_sbm_tensors_epoch"] = _REG_EPOCH[0]
+        return tuple((p.data_ptr(), p._version) for p in d["_sbm_tensors"])
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)          # .to() / .cuda() / .float(): tensors may have been replaced without a registration
@@ -84,9 +94,7 @@ class ParamTreeModule(nn.Module):
     def _engine(self, key, factory):
         fp = self._fingerprint()
         if fp != self._sbm_fingerprint:
-            for e in self._sbm_engines.values():
-                e.close()
-            self._sbm_engines = {}
+            self.release_engines()
             self._sbm_fingerprint = fp
         eng = self._sbm_engines.get(key)
         if eng is None:
@@ -95,10 +103,17 @@ class ParamTreeModule(nn.Module):
         return eng
 
     def release_engines(self):
-        for e in self._sbm_engines.values():
-            e.close()
-        self._sbm_engines = {}
-        self._sbm_fingerprint = None
+        """Close every cached engine.  `Engine.close()` raises on a tear-down error or an unreported kernel failure: every engine is
+        still closed and the cache is empty afterwards in any case (no dead handle can be fetched later); the first error is re-raised."""
+        engines, self._sbm_engines, self._sbm_fingerprint = list(self._sbm_engines.values()), {}, None
+        first = None
+        for e in engines:
+            try:
+                e.close()
+            except Exception as exc:           # noqa: BLE001 -- collected, re-raised below
+                first = first or exc
+        if first is not None:
+            raise first
 
 
 def as_f32_cuda(t, what):
@@ -108,19 +123,13 @@ def as_f32_cuda(t, what):
     return t.contiguous()
 
 
-def fresh_seed(seed=None, group=None):
+def fresh_seed(seed=None):
     """Philox key of one sampler call.  `None` draws a fresh 64-bit key from torch's default generator, so successive calls get
     independent in-loop noise (as the reference's per-call `torch.randn_like`, sde_helper2.py:47,96), `torch.manual_seed`
-    reproduces a run, and the generator state advances.  Under an initialised process group the ranks must share ONE key -- the noise
-    is a single global stream indexed by the global sample number -- so rank 0's draw is broadcast (every rank still
-    draws, keeping the generators in step); an explicit `seed=` is taken as is and must be the same on every rank."""
+    reproduces a run, and the generator state advances.  Always LOCAL: a sampling helper never issues a collective (a rank-conditional
+    `if rank == 0: sample(...)` inside a distributed job must not hang).  Ranks that shard ONE global batch need one common key -- the
+    noise is a single stream indexed by the global sample number: `distributed.shared_seed()` agrees on it explicitly
+    (`distributed.sample_sharded` is already a collective and does so) and the key is passed down as `seed=`."""
     if seed is not None:
         return int(seed) & 0xFFFFFFFFFFFFFFFF
-    key = torch.empty((), dtype=torch.int64).random_()
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-        k = key.reshape(1).to(dev)
-        dist.broadcast(k, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        key = k.cpu()[0]
-    return int(key.item()) & 0xFFFFFFFFFFFFFFFF
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF

@@ -135,8 +135,7 @@ int sbm_model_destroy(sbm_model* m) {
     if (!errs.empty()) errs += "; ";
     errs += what; errs += ": "; errs += hipGetErrorString(e);
   };
-  static const bool debug_nosync = std::getenv("SBM_DEBUG_DESTROY_NOSYNC") != nullptr;   // tools/destroy_repro.py only: reproduces the round-2 abort
-  if (!debug_nosync) note("hipDeviceSynchronize", hipDeviceSynchronize());
+  note("hipDeviceSynchronize", hipDeviceSynchronize());
   const bool aborted = m->h_abort && __atomic_load_n(m->h_abort, __ATOMIC_RELAXED) != 0u;
   rowrun_release(&m->plan);
   pixrun_release(m->dp);
@@ -214,6 +213,7 @@ static int model_create_impl(int kind, const int* cfg, int batch, int in_pitch, 
   sbm_model* m = new (std::nothrow) sbm_model();
   if (!m) return fail("out of host memory");
   m->kind = kind;
+  prepare_layer_kernels();
   if (kind == SBM_CLG) {                    // guidance MLP: no plan, just the packed matrices
     std::vector<float> packed; std::string err;
     if (!clg_pack(cfg[0], cfg[1], cfg[2], cfg[3], host_tensors, &packed, m->clg_off, &err)) { delete m; return fail("sbm_model_create: " + err); }

@@ -262,6 +262,7 @@ void arm_profile_events(hipEvent_t start, hipEvent_t stop);
 // Raise a kernel's dynamic-LDS limit once per (function, device): the attribute is per device, so a process-wide flag would leave a second
 // device at the 64 KB default.  Cheap when already done (one device query + a set lookup under a mutex).
 void ensure_dynamic_lds(const void* fn, int bytes);
+void prepare_layer_kernels();          // kernels.hip: dynamic-LDS attributes of the per-layer kernels (called by sbm_model_create)
 extern thread_local hipEvent_t g_prof_start, g_prof_stop;   // armed by arm_profile_events (kernels.hip)
 void launch_set_counter(int* step_counter, int value, hipStream_t st);
 void launch_axpy_noise(const StepArgs& a, float ca, float cb, float sdiv, unsigned mod_mask, int per_mod, hipStream_t st);

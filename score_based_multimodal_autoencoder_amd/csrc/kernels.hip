@@ -1708,6 +1708,13 @@ static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, 
   return nullptr;
 }
 
+// Dynamic-LDS limits of the per-layer kernels that need more than the default 64 KB window: set at model creation (per device, outside any
+// stream capture), never at launch time.
+void prepare_layer_kernels() {
+  ensure_dynamic_lds(reinterpret_cast<const void*>(dwconv7_t8_kernel), 64 * 1024);
+  ensure_dynamic_lds(reinterpret_cast<const void*>(linattn_lds4_kernel), 3 * 320 * 128);     // + 18 KB static: within the 160 KB of a CU
+}
+
 const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ext_out, hipStream_t st) {
   const Plan& plan = *dp.plan; const Op& op = plan.ops[idx]; const float* prm = dp.prm; float* ws = dp.ws;
   if (op.chain) return launch_chain(dp, idx, 1, st);
@@ -1720,7 +1727,6 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
         if (o.in.W != 16 || o.in.H != 16 || (o.in.C + 31) / 32 != o.stat_slabs || (o.in.C & 3)) return "dwconv7: slab statistics need a 16x16 tensor in slabs of 32 channels";
         SBM_KLAUNCH(dwconv7_t16_kernel, dim3(o.B, o.stat_slabs), dim3(256), 0, st, d);
       } else if (o.in.W == 8 && o.in.H == 8 && o.in.C / 4 <= 32 && !getenv("SBM_NO_DWT8")) {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(dwconv7_t8_kernel), 64 * 1024);
         SBM_KLAUNCH(dwconv7_t8_kernel, dim3(o.B), dim3(256), (size_t)(64 + 49) * (o.in.C / 4) * 16, st, d);
       } else if (o.in.W == 8 && o.in.C / 4 <= 64 && o.in.C / 4 >= 4 && (256 % (o.in.C / 4)) == 0 && !getenv("SBM_NO_DW8")) {
         SBM_KLAUNCH(dwconv7_w8_kernel, dim3(o.in.H * 2, ceil_div(o.B, d.spb)), dim3(256), 0, st, d);
@@ -1734,7 +1740,6 @@ const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ex
       if (o.dh != 32) return "attention: dim_head must be 32";
       if (op.kind == OP_ATTN && a.n > 64) return "softmax attention: more than 64 positions";
       if (op.kind == OP_LINATTN && a.n > 16 && a.n <= 320 && (a.ldq & 3) == 0 && (a.n <= 64 || !getenv("SBM_NO_LINATTN_BIG"))) {
-        ensure_dynamic_lds(reinterpret_cast<const void*>(linattn_lds4_kernel), 3 * 320 * 128);     // + 18 KB static: within the 160 KB of a CU
         SBM_KLAUNCH(linattn_lds4_kernel, dim3(o.B * o.heads), dim3(256), (size_t)3 * a.n * 128, st, a);
       }
       else if (op.kind == OP_LINATTN && a.n <= 64 && (a.ldq & 3) == 0) SBM_KLAUNCH(linattn_lds_kernel, dim3(o.B * o.heads), dim3(64), 0, st, a);

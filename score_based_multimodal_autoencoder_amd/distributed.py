@@ -49,16 +49,32 @@ def all_gather_cat(t, group=None):
     return out
 
 
-def sample_sharded(sample_fn, global_batch, group=None, gather=True):
+def shared_seed(group=None, seed=None):
+    """ONE Philox key for all ranks of `group`: rank 0's draw from torch's default generator (or its `seed`), broadcast.  Every rank
+    draws, so the generators stay in step.  This IS a collective -- call it where every rank of the group passes (the sampling helpers
+    themselves never do: `_module.fresh_seed` is local), then hand the key down as `seed=`."""
+    from ._module import fresh_seed
+    key = fresh_seed(seed)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        k = torch.tensor([key - (1 << 64) if key >= (1 << 63) else key], dtype=torch.int64, device=dev)
+        dist.broadcast(k, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        key = int(k.cpu()[0].item()) & 0xFFFFFFFFFFFFFFFF
+    return key
+
+
+def sample_sharded(sample_fn, global_batch, group=None, gather=True, share_seed=False):
     """Run `sample_fn(start, count)` on this rank's rows and gather once.
 
     sample_fn must be a function of the GLOBAL row indices only (e.g. uncond_sampler(...,
     sample_offset=start) followed by the decoders); it returns a tensor or a tuple of tensors with
-    `count` rows each."""
+    `count` rows each.  With `share_seed=True` the ranks first agree on one fresh Philox key
+    (`shared_seed`) and the call is `sample_fn(start, count, seed)`: the way to draw fresh noise for a
+    sharded batch without choosing a seed by hand."""
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     start, count = shard_range(global_batch, rank, world)
-    local = sample_fn(start, count)
+    local = sample_fn(start, count, shared_seed(group)) if share_seed else sample_fn(start, count)
     if not gather:
         return local
     if isinstance(local, (tuple, list)):

@@ -203,6 +203,20 @@ assert torch.equal(a, ra) and torch.equal(b, rb), "gathered result differs from 
 assert D.shard_range(G, rank, world) == (rank * 6, 6)
 s = D.langevin_norm_allreduce(torch.tensor([1.0 + rank, 2.0]))
 assert torch.equal(s, torch.tensor([3.0, 4.0]))
+# one fresh key for all ranks, agreed explicitly (the sampling helpers themselves never issue a collective: fresh_seed is local)
+from score_based_multimodal_autoencoder_amd._module import fresh_seed
+torch.manual_seed(100 + rank)
+local = fresh_seed(None)
+torch.manual_seed(100 + rank)
+key = D.shared_seed()
+torch.manual_seed(100)
+assert key == fresh_seed(None), "shared_seed is not rank 0's draw"
+assert (key == local) == (rank == 0)
+assert D.shared_seed(seed=(1 << 64) - 5 + rank) == (1 << 64) - 5
+got = D.sample_sharded(lambda start, count, seed: torch.full((count, 1), float(seed % 1000)), G, share_seed=True)
+assert got.shape == (G, 1) and bool((got == got[0]).all()), "ranks sampled under different keys"
+if rank == 0:
+    fresh_seed(None)          # a rank-conditional call must not hang: no collective inside
 try:
     D.shard_range(13, rank, world); raise SystemExit("uneven split accepted")
 except ValueError:
@@ -242,6 +256,18 @@ def test_bench_launches_its_own_ranks_when_no_launcher_is_present():
     # with a launcher's environment the script must NOT spawn again: one process, world size from the environment
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry"], env=env, capture_output=True, text=True, timeout=300)
     assert r1.returncode == 0 and json.loads(r1.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_launcher_ends_the_siblings_of_a_rank_that_dies():
+    """one rank dying at start-up must not leave the others in the rendezvous until the collective time-out: the launcher
+    polls all children, terminates the rest, returns non-zero and shows the failed rank."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SBM_BENCH_DRY_FAIL_RANK"] = "1"
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "rank 1 exited with 3" in r.stderr, (r.returncode, r.stderr[-1000:])
+    assert time.monotonic() - t0 < 120
 
 
 def test_pixel_kernel_register_audit(tmp_path):
@@ -301,4 +327,36 @@ def test_engine_fingerprint_sees_every_kind_of_weight_change_and_does_not_walk_t
     assert fp4 != fp3 and m.__dict__["_sbm_tensors"] is not lst                       # the list was re-collected
     assert any(t is getattr(owner, name.split(".")[-1]) for t in m.__dict__["_sbm_tensors"])
     m.double()
-    assert m._fingerprint() != fp4
+    fp5 = m._fingerprint()
+    assert fp5 != fp4
+    # a sub-module replaced by an already-constructed one, and a write that bypasses registration (`_parameters[name] = t`)
+    other = Unet(dim=8, channels=2, dim_mults=(1, 2)).eval().double()
+    child = next(n for n, mm in m.named_children() if sum(1 for _ in mm.parameters()) > 0)
+    setattr(m, child, getattr(other, child))
+    fp6 = m._fingerprint()
+    assert fp6 != fp5 and any(t is next(getattr(other, child).parameters()) for t in m.__dict__["_sbm_tensors"])
+    name = next(n for n, _ in m.named_parameters())
+    owner = m
+    for part in name.split(".")[:-1]:
+        owner = getattr(owner, part)
+    new = torch.nn.Parameter(torch.ones_like(owner._parameters[name.split(".")[-1]]))
+    owner._parameters[name.split(".")[-1]] = new                                       # no registration hook fires
+    assert m._fingerprint() != fp6 and any(t is new for t in m.__dict__["_sbm_tensors"])
+
+
+def test_release_engines_closes_all_and_empties_the_cache_even_when_a_close_raises():
+    """Engine.close() may raise (tear-down error, unreported kernel failure); the cache must not keep dead engines."""
+    m = Unet(dim=8, channels=2, dim_mults=(1, 2)).eval()
+    closed = []
+
+    class E:
+        def __init__(self, bad): self.bad = bad
+        def close(self):
+            closed.append(self)
+            if self.bad: raise RuntimeError("tear-down failed")
+    m._sbm_engines = {1: E(True), 2: E(False), 3: E(True)}
+    m._sbm_fingerprint = m._fingerprint()
+    with pytest.raises(RuntimeError, match="tear-down failed"):
+        m.release_engines()
+    assert len(closed) == 3 and m._sbm_engines == {} and m._sbm_fingerprint is None
+    m.release_engines()                                                                # nothing left: no error
