@@ -784,6 +784,22 @@ int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_
   return 0;
 }
 
+// The plan's input conversion op when the sampler's update kernels can write its output themselves (sampler.hip store_pbc): an unconditional
+// loop over a state without spatial padding and with rows of a multiple of four elements; -1 otherwise (the forward then converts as usual).
+static int sampler_cvt_op(const sbm_model* m, bool conditional) {
+  static const bool off = std::getenv("SBM_NO_FUSED_CVT") != nullptr;
+  if (conditional || off) return -1;
+  const Plan& P = m->plan;
+  for (int i = 0; i < (int)P.ops.size(); ++i) {
+    if (P.ops[i].kind != OP_NCHW_TO_PBC) continue;
+    const CvtOp& cv = P.ops[i].cv;
+    const int Ho = cv.out.H, Wo = cv.rowpack ? cv.Wo : cv.out.W;
+    if (cv.pad_y || cv.pad_x || Ho != cv.Hn || Wo != cv.Wn || (cv.Wn & 3) || cv.C != P.out_C || cv.Hn != P.out_H || cv.Wn != P.out_W) return -1;
+    return i;
+  }
+  return -1;
+}
+
 // one full sampling step enqueued on `st` (graph-capturable: no allocation, no sync, step index read on device)
 static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sampler_cfg& c, const float* timesteps, const float* alphas, const float* noise,
                                 float* x, float* x_mean, hipStream_t st, bool time_table, const sbm_cond_cfg* cond = nullptr, const float* z_obs = nullptr,
@@ -797,31 +813,44 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
   a.x_out = x; a.mean_out = x_mean; a.norms = m->d_norms; a.seed = c.seed; a.sample_offset = c.sample_offset; a.B = B; a.CHW = CHW; a.sde = sp;
   a.noise_step_stride = (long long)dps * B * CHW;
   const bool guided = guide && !guide->empty();
+  // The update kernels keep the score net's converted input current (sampler.hip store_pbc), so the forward skips its conversion launch:
+  // unconditional loops only (the conditional ones rewrite x in front of the forward).  sampler_run_impl converts the initial state once.
+  const int cvt = sampler_cvt_op(m, cond != nullptr);
+  if (cvt >= 0) {
+    const CvtOp& cv = P.ops[cvt].cv;
+    a.pbc_out = m->d_ws + cv.out.off; a.pbc_ld = cv.out.ld; a.pbc_rowpack = cv.rowpack; a.pbc_Cv = cv.rowpack ? cv.Cpad : cv.out.C; a.pbc_H = cv.Hn; a.pbc_W = cv.Wn;
+  }
+  const int skip = cvt >= 0 ? 4 : 0;
   auto score_eval = [&]() -> const char* {
     const char* e;
     if (time_table) {
       if (guided) launch_fill_time(tbuf, timesteps, m->d_counter, B, st);   // the guidance networks take the step's time per sample (the score net reads the table)
-      e = run_plan(m->dp, x, tbuf, m->d_score, st, 1);                      // the time path comes from the table
+      e = run_plan(m->dp, x, tbuf, m->d_score, st, 1 | skip);               // the time path comes from the table
     } else {
       launch_fill_time(tbuf, timesteps, m->d_counter, B, st);
-      e = run_plan(m->dp, x, tbuf, m->d_score, st);
+      e = run_plan(m->dp, x, tbuf, m->d_score, st, skip);
     }
     if (e) return e;
     if (guided)                    // classifier / energy guidance on the score just evaluated, at the same x and t (sde_helper2.py:283-312, 65-94)
       for (ClgArgs a : *guide) { a.x = x; a.t = tbuf; a.score = m->d_score; if ((e = launch_clg(a, st))) return e; }
     return nullptr;
   };
-  auto corrector = [&](int first_draw) -> const char* {
+  // the step's LAST update kernel also advances the step counter (its last workgroup, sampler.hip advance_by_last_workgroup)
+  unsigned* ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(m->d_counter) + 48);
+  auto corrector = [&](int first_draw, bool last) -> const char* {
     for (int i = 0; i < c.n_steps; ++i) {
       const char* e = score_eval(); if (e) return e;
       a.draw = first_draw + i; a.noise_draw_off = (long long)(first_draw + i) * B * CHW;
+      const bool adv = last && i == c.n_steps - 1;
+      a.adv_counter = adv ? m->d_counter : nullptr; a.adv_ticket = adv ? ticket : nullptr;
       launch_langevin_step(a, st);
     }
     return nullptr;
   };
-  auto predictor = [&](int draw) -> const char* {
+  auto predictor = [&](int draw, bool last) -> const char* {
     const char* e = score_eval(); if (e) return e;
     a.draw = draw; a.noise_draw_off = (long long)draw * B * CHW;
+    a.adv_counter = last ? m->d_counter : nullptr; a.adv_ticket = last ? ticket : nullptr;
     launch_em_step(a, st);
     return nullptr;
   };
@@ -834,13 +863,12 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
     launch_renoise(r, z_obs, cond->obs_mask, CHW / cond->n_mod, st, cond->noise_obs ? 0 : 1);
   }
   if (c.order == 0) {                      // sde_helper2.uncond_sampler: corrector, then predictor
-    if (c.pc && (e = corrector(0))) return e;
-    if ((e = predictor(c.pc ? c.n_steps : 0))) return e;
+    if (c.pc && (e = corrector(0, false))) return e;
+    if ((e = predictor(c.pc ? c.n_steps : 0, true))) return e;
   } else {                                 // train_poly_unet_cont.uncond_sampler: predictor, then corrector
-    if ((e = predictor(0))) return e;
-    if (c.pc && (e = corrector(1))) return e;
+    if ((e = predictor(0, !c.pc))) return e;
+    if (c.pc && (e = corrector(1, true))) return e;
   }
-  launch_advance(m->d_counter, st);
   return nullptr;
 }
 
@@ -913,6 +941,8 @@ static int sampler_run_impl(sbm_model* m, const sbm_sde_cfg* sde, const sbm_samp
     if (int rc = build_time_table(m, timesteps, sde->N, x_inout, st, "sbm_sampler_run")) return rc;
     guard.armed = true;
   }
+  { const int cvt = sampler_cvt_op(m, cond != nullptr);      // the loop's forwards skip the conversion: the initial state is converted here, once
+    if (cvt >= 0 && (e = launch_op(m->dp, cvt, x_inout, nullptr, st))) return fail(std::string("sbm_sampler_run: ") + e); }
   if (cfg->use_graph && n_run > 1) {
     HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     e = enqueue_step(m, sp, *cfg, timesteps, alphas, noise, x_inout, x_mean_out, st, time_table, cond, z_obs, guide);

@@ -191,7 +191,7 @@ const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, 
 
 // Enqueue every op of the plan on `st`.  Returns nullptr or a static error string.  No allocation, no
 // synchronisation: safe to capture into a hipGraph.
-const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops = 0);   // time_ops: 0 all ops, 1 skip the time path, 2 only the time path
+const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops = 0);   // time_ops: 0 all ops, 1 skip the time path, 2 only the time path; + 4: skip the input conversion op
 const char* launch_op(const DevPlan& dp, int op_index, const float* ext_in, float* ext_out, hipStream_t st);
 
 extern unsigned long long* g_gemm_dbg;
@@ -230,6 +230,11 @@ struct StepArgs {
   int draw;                // which draw of the step this is (0 = predictor, 1.. = corrector iterations)
   int B, CHW;
   SdeParams sde;
+  // Sampler loop only.  pbc_out: the new state is ALSO stored in the score net's converted input layout (the plan's NCHW -> PBC op, row-packed
+  // or plain), so the next step's forward skips its conversion launch.  adv_counter: the LAST workgroup of this launch to finish advances
+  // the step counter (every workgroup has read it by then), which replaces the one-thread advance launch behind the step.
+  float* pbc_out; int pbc_ld, pbc_Cv, pbc_rowpack, pbc_H, pbc_W;
+  int* adv_counter; unsigned* adv_ticket;
 };
 
 // classifier / energy guidance MLP (guidance.hip): forward + input-VJP of cl_out.mean() + in-place score update

@@ -1854,7 +1854,9 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
     if (hipMemcpyAsync(dp.ws + plan.time_off, t_dev, sizeof(float) * plan.B, hipMemcpyDeviceToDevice, st) != hipSuccess) return "time copy failed";
   if (plan.aux_off >= 0 && dp.aux)
     if (hipMemcpyAsync(dp.ws + plan.aux_off, dp.aux, sizeof(float) * plan.B * plan.aux_C, hipMemcpyDeviceToDevice, st) != hipSuccess) return "aux copy failed";
-  auto skipped = [&](int i) { return (time_ops == 1 && plan.ops[i].time_path) || (time_ops == 2 && !plan.ops[i].time_path); };
+  const bool skip_cvt = (time_ops & 4) != 0;        // the caller keeps the converted input current itself (sampler loop)
+  time_ops &= 3;
+  auto skipped = [&](int i) { return (time_ops == 1 && plan.ops[i].time_path) || (time_ops == 2 && !plan.ops[i].time_path) || (skip_cvt && plan.ops[i].kind == OP_NCHW_TO_PBC); };
   for (int i = 0; i < (int)plan.ops.size();) {
     int n = 1;
     const char* e;

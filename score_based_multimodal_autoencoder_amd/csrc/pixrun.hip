@@ -33,6 +33,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "device.h"
@@ -47,6 +48,8 @@ constexpr int PNT = 512, PNW = 8;         // threads / waves per workgroup (2 wa
 constexpr int PD = 4;                     // ring depth in steps (4 KB per wave and step)
 constexpr int PCS = 272;                  // floats per LDS chunk: 17 rows x 16 k
 constexpr int PIX_STAGE = 101;
+constexpr int PIX_VEC = 102;              // a GEMM with ONE output pixel as a vector-ALU mat-vec (no MFMA, no AGPR ring): see the kernel
+constexpr int PIX_DW1 = 103, PIX_GNR1 = 104;   // the depth-wise op / GroupNorm + residual at ONE position, inside a run of PIX_VEC ops
 constexpr int P_RED_F = PNW * 512, P_STAT_SLOTS = 64, P_SCR_F = 4352;
 
 struct PixStep { unsigned w_off; unsigned a_sel; };   // w_off: float offset (fragment arena) of the step's block for column group 0 of the pass;
@@ -78,20 +81,15 @@ struct PixOpD {
   float* out_g; float2* stat_g;          // non-null: the result / its statistics also go to the workspace
   DwArgs dw; GnResArgs gr; AttnArgs at;
   const float* st_src; const float2* st_part; int st_ld, st_C, st_P, st_lds, st_stat, st_nparts;
+  // PIX_VEC: out[n] = sum_k a[k] W[k][n] over 512 threads = N columns x S K-slices (N S = 512); steps of 8 KB: thread (column, slice) takes one float4 of weights
+  // and the matching four activations of its slice.  Source 1 (v_n1 steps; GroupNorm folded as in the MFMA path) and source 2 (v_n2 steps, raw).
+  int v_run, v_stream, v_slots, v_pad2;   // on the FIRST op of a run: program ops in the run, step index where the run's slot table begins, its slots
+  int v_step_base, v_n1, v_n2, v_sshift;  // v_n1: slots (four steps each) of this op, a multiple of 4
+  int v_Npad, v_nstore, v_act, v_ldo, v_gn, v_res_lds;     // v_res_lds: float offset of the residual ROW (-1 none)
+  float v_gn_inv; int v_pad;
+  const float* v_bias; const float* v_gn_s; const float* v_gn_b1;
 };
 
-__device__ __forceinline__ float pix_act(int act, float v) {
-  switch (act) {
-    case ACT_GELU: return 0.5f * v * (1.0f + sbm_erf(v * 0.70710678118654752440f));
-    case ACT_LRELU02: return v >= 0.f ? v : 0.2f * v;
-    case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    case ACT_SILU: return v / (1.0f + expf(-v));
-    case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));
-    case ACT_LRELU01: return v >= 0.f ? v : 0.1f * v;
-    default: return v;
-  }
-}
 // The step / item / op tables are read through the CONSTANT address space: with a uniform address that is always a scalar load (s_load).
 // Read as ordinary global memory they turn into vector loads -- the kernel stores through pointers it has loaded (op.out_g, ...), so hipcc
 // cannot prove the tables unclobbered -- and every vector load drags a compiler-placed s_waitcnt vmcnt(0) into the K loop, which drains
@@ -101,6 +99,10 @@ __device__ __forceinline__ PixStep ldc_step(const PixStep* p) {
   const i32x2p v = *(const __attribute__((address_space(4))) i32x2p*)(unsigned long long)p;
   return PixStep{(unsigned)v[0], (unsigned)v[1]};
 }
+typedef int i32x8p __attribute__((ext_vector_type(8)));
+// eight table words in ONE scalar load.  The step groups of the one-position runs are stored BLOCKED -- the eight weight offsets of a group, then
+// its eight activation selectors -- so that the loader and the consumer each need eight SGPRs, not sixteen (the kernel is short of them)
+__device__ __forceinline__ i32x8p ldc_x8(const void* p) { return *(const __attribute__((address_space(4))) i32x8p*)(unsigned long long)p; }
 template <typename T> __device__ __forceinline__ T ldc(const T* p) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8, "ldc: 4- or 8-byte fields");
   if constexpr (sizeof(T) == 4) { const int v = *(const __attribute__((address_space(4))) int*)(unsigned long long)p; T r; __builtin_memcpy(&r, &v, 4); return r; }
@@ -122,6 +124,8 @@ __device__ __forceinline__ int pix_at(int k, int r) { return (k >> 4) * PCS + r 
 // ... of a tensor of up to 64 rows: four 17-row sub-slabs (rows 16 s .. 16 s + 15 in sub-slab s), `sub` floats apart -- so every chunk keeps
 // its own zero row and the GEMM's row gather stays one table look-up whatever the resolution
 __device__ __forceinline__ int pix_at2(int k, int r, int sub) { return (r >> 4) * sub + (k >> 4) * PCS + (r & 15) * 16 + (k & 15); }
+// a load through a pointer that was itself read from a table: the compiler only knows a generic pointer (flat_load); this says "global"
+__device__ __forceinline__ float ldg(const float* p, int i) { return ((const __attribute__((address_space(1))) float*)(unsigned long long)p)[i]; }
 __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed char)((w[r >> 2] >> (8 * (r & 3))) & 0xff); }
 
 // ---- the weight ring: AGPRs.  With any AGPR in use hipcc splits the 256 registers of a 2-waves-per-SIMD kernel 128 / 128 (no attribute of
@@ -171,6 +175,19 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
     else if ((r) == 1) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71); \
     else if ((r) == 2) PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87); \
     else PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, 88, 89, 90, 91, 92, 93, 94, 95, 96, 97, 98, 99, 100, 101, 102, 103); } while (0)
+// Timing-only experiment builds (tools/build_variant.sh; the results are WRONG): -DPIX_EXP_NOLOAD drops the K loops' weight loads,
+// -DPIX_EXP_NOMFMA their matrix instructions -- what each side costs alone.
+#ifdef PIX_EXP_NOMFMA
+#undef PIX_MFMA16
+#undef PIX_MFMA4
+#define PIX_MFMA16(acc0, acc1, a0, a1, ...) asm volatile("s_waitcnt vmcnt(12)" : "+v"(acc0), "+v"(acc1) : "v"(a0[0]), "v"(a1[0]))
+#define PIX_MFMA4(acc0, acc1, q0, q1, q2, q3, ...) asm volatile("s_waitcnt vmcnt(12)" : "+v"(acc0), "+v"(acc1) : "v"(q0[0]), "v"(q1[0]), "v"(q2[0]), "v"(q3[0]))
+#endif
+#ifdef PIX_EXP_NOLOAD
+#define PIX_KLOAD_SLOT(r, base_, off) do { asm volatile("" :: "s"(base_), "v"(off)); } while (0)
+#else
+#define PIX_KLOAD_SLOT(r, base_, off) PIX_LOAD_SLOT(r, base_, off)
+#endif
 // epilogue operands of one output quad: bias, folded-GroupNorm S and B1 (three dwordx4) into a[BASE .. BASE + 11]
 #define PIX_ELOAD(pb, ps, pg, A0, A3, A4, A7, A8, A11) \
   asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off\n\t" \
@@ -180,6 +197,37 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
 #define PIX_EREAD4(dst, A0, A1, A2, A3) \
   asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3 \
                : "=v"(dst[0]), "=v"(dst[1]), "=v"(dst[2]), "=v"(dst[3]))
+
+// The one-position runs (PIX_VEC) stream their weights through the SAME AGPR ring: a slot = four 8 KB steps = one dwordx4 per thread and step, the
+// four of them 8 KB apart (four scalar bases; a mat-vec's steps are contiguous in the arena); consumed through v_accvgpr_read into four float4.
+#define PIX_VRING_LOAD(v0, b0, b1, b2, b3, A0, A3, A4, A7, A8, A11, A12, A15, CLOB) \
+  asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, %1\n\t" \
+               "global_load_dwordx4 a[" #A4 ":" #A7 "], %0, %2\n\t" \
+               "global_load_dwordx4 a[" #A8 ":" #A11 "], %0, %3\n\t" \
+               "global_load_dwordx4 a[" #A12 ":" #A15 "], %0, %4" \
+               :: "v"(v0), "s"(b0), "s"(b1), "s"(b2), "s"(b3) : CLOB)
+#define PIX_VLOAD_SLOT(r, base_) do { \
+    const float* b1_ = (base_) + 2048; const float* b2_ = (base_) + 4096; const float* b3_ = (base_) + 6144; \
+    if ((r) == 0) PIX_VRING_LOAD(vo0, base_, b1_, b2_, b3_, 40, 43, 44, 47, 48, 51, 52, 55, PIX_CLOB_0); \
+    else if ((r) == 1) PIX_VRING_LOAD(vo0, base_, b1_, b2_, b3_, 56, 59, 60, 63, 64, 67, 68, 71, PIX_CLOB_1); \
+    else if ((r) == 2) PIX_VRING_LOAD(vo0, base_, b1_, b2_, b3_, 72, 75, 76, 79, 80, 83, 84, 87, PIX_CLOB_2); \
+    else PIX_VRING_LOAD(vo0, base_, b1_, b2_, b3_, 88, 91, 92, 95, 96, 99, 100, 103, PIX_CLOB_3); } while (0)
+// One step: four ring registers out of the AGPRs and straight into the accumulator, in ONE asm statement -- given the values as C++ objects hipcc
+// fetched a whole slot first and, short of VGPRs, parked the surplus in a104 / a105: the pending pass's epilogue operands (the build audit
+// caught it).  The first step of a slot waits for the slot's loads.
+#define PIX_VFMA1(WAIT, B0, B1, B2, B3) \
+  asm volatile(WAIT "v_accvgpr_read_b32 %4, a" #B0 "\n\tv_accvgpr_read_b32 %5, a" #B1 "\n\tv_accvgpr_read_b32 %6, a" #B2 "\n\tv_accvgpr_read_b32 %7, a" #B3 "\n\t" \
+               "v_fmac_f32 %0, %4, %8\n\tv_fmac_f32 %1, %5, %9\n\tv_fmac_f32 %2, %6, %10\n\tv_fmac_f32 %3, %7, %11" \
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "=&v"(vt0), "=&v"(vt1), "=&v"(vt2), "=&v"(vt3) \
+               : "v"(av[0]), "v"(av[1]), "v"(av[2]), "v"(av[3]))
+#define PIX_VSTEP(i, B0, B1, B2, B3, B4, B5, B6, B7, B8, B9, B10, B11, B12, B13, B14, B15) do { \
+    if ((i) == 0) PIX_VFMA1("s_waitcnt vmcnt(12)\n\t", B0, B1, B2, B3); else if ((i) == 1) PIX_VFMA1("", B4, B5, B6, B7); \
+    else if ((i) == 2) PIX_VFMA1("", B8, B9, B10, B11); else PIX_VFMA1("", B12, B13, B14, B15); } while (0)
+#define PIX_VFMA_STEP(r, i) do { \
+    if ((r) == 0) PIX_VSTEP(i, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54, 55); \
+    else if ((r) == 1) PIX_VSTEP(i, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71); \
+    else if ((r) == 2) PIX_VSTEP(i, 72, 73, 74, 75, 76, 77, 78, 79, 80, 81, 82, 83, 84, 85, 86, 87); \
+    else PIX_VSTEP(i, 88, 89, 90, 91, 92, 93, 94, 95, 96, 97, 98, 99, 100, 101, 102, 103); } while (0)
 
 // LinearAttention core (unet_model.py:169-175) of one sample with the position count N a compile-time constant: every loop over positions
 // or head channels is fully unrolled, so its LDS reads are in flight together (with run-time bounds each iteration exposed a full LDS
@@ -271,6 +319,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
   float* scr = stat + P_STAT_SLOTS * PNW * 2;            // scratch (LinearAttention contexts)
   unsigned short* rtab = reinterpret_cast<unsigned short*>(scr + P_SCR_F);   // [nrowtab][16]: source row of output row r in 16-float units from the slab origin (16 = the zero row)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid0 = tid;
   const int b = blockIdx.x;
   for (int i = tid; i < act_floats + P_RED_F; i += PNT) lds[i] = 0.f;
   for (int i = tid; i < nrowtab * 16; i += PNT) rtab[i] = rowtab[i];
@@ -289,13 +338,14 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
   auto lane_off = [&](const PixItem* it) { return (unsigned)(((wave & ((1 << ldc(&it->gshift)) - 1)) * ldc(&it->grp_stride) + lane * 4) * 4); };   // bytes
   auto slice_steps = [&](const PixItem* it) { return steps + ldc(&it->step_base) + (wave >> (ldc(&it->gshift) + ldc(&it->rshift))) * ldc(&it->nkp); };
   // output quads of a pass owned by this thread: (row, 4 columns) x 2
-  struct Quads { int row[2], prow[2], col[2]; bool ok[2]; };
+  struct Quads { int row[2], prow[2], col[2]; bool ok[2]; int total; };      // total: output quads of the pass (wave-uniform)
   auto quads_of = [&](const PixItem* it) {
     Quads q;
     const bool small = (ldc(&it->flags) & PIF_SMALL) != 0;
     const int gw = small ? 64 : 32, qshift = ldc(&it->gshift) + (small ? 4 : 3), rshift = ldc(&it->rshift);
     const int prow = ldc(&it->P_out) < (16 << rshift) ? ldc(&it->P_out) : (16 << rshift);      // rows of the pass
     const int total = prow << qshift;
+    q.total = total;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int idx = tid + j * PNT, idc = idx < total ? idx : total - 1;
@@ -313,6 +363,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     const float* bias = ldc(&it->bias); const float* gs = ldc(&it->gn_s); const float* gb = ldc(&it->gn_b1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
+      if (wave * 64 + j * PNT >= q.total) continue;       // no lane of this wave owns a quad j of this pass (wave-uniform: nothing to fetch)
       const int colc = q.col[j] < npad - 4 ? q.col[j] : npad - 4;
       const float* pb = bias + colc; const float* ps = gs + (long long)q.row[j] * rst + colc; const float* pg = gb + (long long)q.row[j] * rst + colc;
       if (j == 0) PIX_ELOAD(pb, ps, pg, 104, 107, 108, 111, 112, 115); else PIX_ELOAD(pb, ps, pg, 116, 119, 120, 123, 124, 127);
@@ -336,6 +387,9 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     const int kind = ldc(&op.kind);
     if (dbg && b == 0 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();
     if (kind == PIX_STAGE) {
+      // (an opaque copy of the thread index: what is derived from it here stays here.  hipcc hoists every cheap tid expression of every branch
+      //  in front of the op loop and keeps it for the whole kernel -- forty of them in a0 .. a39, and the ones that did not fit in scratch)
+      int tid = tid0; asm volatile("" : "+v"(tid));
       const int C4 = ldc(&op.st_C) >> 2, st_P = ldc(&op.st_P), st_ld = ldc(&op.st_ld), st_lds = ldc(&op.st_lds), st_stat = ldc(&op.st_stat), st_sub = ldc(&op.st_sub);
       const float* src = ldc(&op.st_src);
       for (int idx = tid; idx < st_P * C4; idx += PNT) {
@@ -352,6 +406,8 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       continue;
     }
     if (kind == OP_DWCONV7) {
+      int tid = tid0; asm volatile("" : "+v"(tid));
+      const int lane = tid & 63;
       // depth-wise 7x7 over an image of at most 4x4: the window covers the whole image.  Task = (channel, output row py): its W outputs
       // need the H x (2 W - 1) weights w[qy - py + 3][d + 3], each loaded once (coalesced over the channels, all issued before the first
       // is used: dead taps read a clamped address and are masked afterwards), and the channel's H W inputs.
@@ -399,6 +455,15 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             if (dw_out) *reinterpret_cast<sbm_f32x2*>(dw_out + ((long long)p * B + b) * ldo + c) = v;
             s += v.x; s += v.y; qq += v.x * v.x; qq += v.y * v.y;
           }
+        }
+      } else if (H == 1 && W == 1) {
+        // one position: the centre tap (unet_model.py:115 at 1x1; SURVEY appendix A "degenerate sizes")
+        for (int c = tid; c < C; c += PNT) {
+          const float a = fmaf(lds[in_lds + pix_at(c, 0)], dw_w[24 * C + c], 0.f);
+          const float v = a + (dw_bias[c] + (cond ? cond[c] : 0.f));
+          lds[out_lds + pix_at(c, 0)] = v;
+          if (dw_out) dw_out[(long long)b * ldo + c] = v;
+          s += v; qq += v * v;
         }
       } else {
       for (int task = tid; task < C * H; task += PNT) {
@@ -455,6 +520,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       continue;
     }
     if (kind == OP_GN_RES) {
+      int tid = tid0; asm volatile("" : "+v"(tid));
       float su, sq;
       stat_sum(ldc(&op.gn_stat), &su, &sq);
       const float inv_count = ldc(&op.gr.inv_count);
@@ -479,12 +545,174 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       continue;
     }
     if (kind == OP_LINATTN) {
+      int tid = tid0; asm volatile("" : "+v"(tid));
       // LinearAttention core (unet_model.py:169-175) of one sample: n <= 16 positions, heads x 32 channels; q | k | v in one slab
       const int n = ldc(&op.at.n), heads = ldc(&op.at.heads), hd = heads * 32, in_lds = ldc(&op.in_lds), out_lds = ldc(&op.out_lds), aldo = ldc(&op.at.ldo);
       const float scale = ldc(&op.at.scale);
       float* aout = ldc(&op.out_g) ? ldc(&op.at.out) : nullptr;
       if (n == 16) pix_linattn<16>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
       else pix_linattn<4>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
+      continue;
+    }
+    if (kind == PIX_VEC || kind == PIX_DW1 || kind == PIX_GNR1) {
+      // A RUN of one-position ops (the 1x1 level and the strided convolution that enters it), v_run program ops long.  On the MFMA path such an
+      // op costs 4.4 us around a 1.3 us K loop -- partial tiles through LDS, two barriers, a 512-thread epilogue for 128 .. 256 outputs -- and a
+      // first version of this path that loaded an op's weights when the op began was no faster: a global load that nobody requested ahead costs
+      // 1 .. 3 us here (every workgroup asks the L2 for the same lines at the same moment).  So the run is ONE STREAM: the 8 KB weight steps of
+      // all its mat-vecs back to back (host-built, each op padded to a multiple of 16 steps), pulled through a register ring of two groups of 8
+      // steps that runs 16 steps ahead ACROSS op boundaries, and every op's small operands (bias / folded-GroupNorm tables, depth-wise centre
+      // taps, GroupNorm affine) are requested while the op before it finishes.  A mat-vec: thread = (column, K slice), 4 FMAs per 16-byte weight
+      // load, K slices are adjacent lanes and meet by DPP, the owner applies the epilogue and stores -- one barrier per op.
+      const int run = ldc(&op.v_run);
+      int tid = tid0; asm volatile("" : "+v"(tid));
+      const int lane = tid & 63;
+      // weight stream of the run: slots of four steps, table entries of 8 words {weight offset, weight offset of the slot 4 further on, -, -,
+      // four activation selectors}
+      int nload = ldc(&op.v_slots);                         // slots still to be requested
+      const int* sc = reinterpret_cast<const int*>(steps + ldc(&op.v_stream));     // next slot to consume
+      const unsigned vo0 = (unsigned)tid * 16u;
+      if (nload > 0) {                                      // (a run without a mat-vec leaves the ring -- the next MFMA pass's first steps -- alone)
+#pragma unroll
+        for (int r = 0; r < PD; ++r) { const float* base_ = frag + (unsigned)ldc(sc + 8 * r); PIX_VLOAD_SLOT(r, base_); }
+        nload -= PD;
+      }
+      float pe0 = 0.f, pe1 = 0.f, pe2 = 0.f;
+      // the small per-thread operands of program op `o`, requested one op ahead.  (A macro, not a lambda: captured by a closure the three values
+      // lived on the stack -- scratch -- and every request was followed by a full wait.)  Pointers read from the tables are generic; cast to the
+      // global address space they give global_load, not flat_load.
+#define PIX_REQUEST_SMALL(o_) do { \
+        const PixOpD& o__ = (o_); \
+        const int kd__ = ldc(&o__.kind); \
+        if (kd__ == PIX_VEC) { \
+          const int npad__ = ldc(&o__.v_Npad), c0__ = tid >> ldc(&o__.v_sshift), c__ = c0__ < npad__ ? c0__ : npad__ - 1; \
+          pe0 = ldg(ldc(&o__.v_bias), c__); pe1 = ldg(ldc(&o__.v_gn_s), c__); pe2 = ldg(ldc(&o__.v_gn_b1), c__); \
+        } else if (kd__ == PIX_DW1) { \
+          const int C__ = ldc(&o__.dw.C), c__ = tid < C__ ? tid : C__ - 1; \
+          const float* dwc__ = ldc(&o__.dw.cond); \
+          const float* cond__ = dwc__ ? (cond_tab && ldc(&o__.dw.ctl) ? cond_tab + ldc(&o__.dw.cond_col) : dwc__ + (long long)b * ldc(&o__.dw.cond_ld)) : ldc(&o__.dw.bias); \
+          pe0 = ldg(ldc(&o__.dw.w), 24 * C__ + c__); pe1 = ldg(ldc(&o__.dw.bias), c__); pe2 = ldg(cond__, c__); \
+          if (!dwc__) pe2 = 0.f; \
+        } else { \
+          const int C__ = ldc(&o__.gr.C), c__ = tid < C__ ? tid : C__ - 1; \
+          pe0 = ldg(ldc(&o__.gr.gamma), c__); pe1 = ldg(ldc(&o__.gr.beta), c__); \
+        } } while (0)
+      PIX_REQUEST_SMALL(op);
+      for (int j = 0; j < run; ++j) {
+        const PixOpD& o = ops[k + j];
+        const int kd = ldc(&o.kind);
+        if (dbg && b == 0 && tid == 0 && j > 0) dbg[k + j] = __builtin_amdgcn_s_memtime();
+        const int out_lds = ldc(&o.out_lds), so = ldc(&o.stat_out);
+        float ov = 0.f;                                     // this thread's stored output (0 when it owns none): the op's statistics
+        if (kd == PIX_VEC) {
+          const int sshift = ldc(&o.v_sshift), S = 1 << sshift, slice = tid & (S - 1), col = tid >> sshift;
+          const int aoff = ((slice * 4) >> 4) * PCS + ((slice * 4) & 15);
+          const bool gn = ldc(&o.v_gn) != 0;
+          float mean = 0.f, rstd = 1.f, inv_r = 1.f;
+          if (gn) {
+            float su, sq;
+            stat_sum(ldc(&o.gn_stat), &su, &sq);
+            const float ginv = ldc(&o.v_gn_inv);
+            const double mean_d = (double)su * (double)ginv;
+            double var = (double)sq * (double)ginv - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
+            mean = (float)mean_d; rstd = rsqrtf((float)var + 1e-5f); inv_r = sqrtf((float)var + 1e-5f);
+          }
+          f32x4p acc = {0.f, 0.f, 0.f, 0.f};
+          // a group of 8 steps out of one half of the ring, then that half's refill 16 steps further down the stream (the next op's first
+          // groups when this op has no more).  Source-2 steps (bit 31: the fused 1x1 residual conv, which enters unnormalised) are scaled by
+          // 1 / rstd so that the common GroupNorm scaling cancels, as on the MFMA path.
+          // one slot: four steps out of the ring, then the slot's refill four slots further down the stream -- or, once the run's stream is
+          // exhausted, with the next MFMA pass's first steps, which the ring held when the run began.  The activations are requested in front
+          // of the wait.  Source-2 steps (bit 31: the fused 1x1 residual conv, which enters unnormalised) are scaled by 1 / rstd so that the
+          // common GroupNorm scaling cancels, as on the MFMA path.
+          auto slots4 = [&](auto sc_tag) __attribute__((always_inline)) {
+            constexpr bool SC = decltype(sc_tag)::value;
+#pragma unroll
+            for (int r = 0; r < PD; ++r) {
+              const i32x8p e = ldc_x8(sc);
+              f32x4p a[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4p*>(__builtin_assume_aligned(lds + ((unsigned)e[4 + i] & 0x7fffffffu) + aoff, 16));
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                f32x4p av = a[i];
+                if (SC) { const float f = e[4 + i] < 0 ? inv_r : 1.0f; av *= f; }
+                float vt0, vt1, vt2, vt3;
+                PIX_VFMA_STEP(r, i);
+              }
+              sc += 8;
+              if (nload > 0) { const float* base_ = frag + (unsigned)e[1]; PIX_VLOAD_SLOT(r, base_); --nload; }
+              else { const PixStep pe_ = ldc_step(st_c + r); const float* base_ = frag + pe_.w_off; PIX_LOAD_SLOT(r, base_, off_c); }
+            }
+          };
+          const int ns = ldc(&o.v_n1);                      // slots of this op, a multiple of 4
+          if (gn && ldc(&o.v_n2) > 0) for (int si = 0; si < ns; si += PD) slots4(std::true_type{});
+          else for (int si = 0; si < ns; si += PD) slots4(std::false_type{});
+          float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+          if (S >= 2) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+          if (S >= 4) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+          if (S >= 8) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xF, 0xF, true));   // row_half_mirror
+          const int nstore = ldc(&o.v_nstore), res_lds = ldc(&o.v_res_lds);
+          if (gn) t = t * rstd + (pe2 - (mean * rstd) * pe1);
+          t += pe0;
+          const bool own = slice == 0 && col < nstore;
+          const int colc = col < nstore ? col : 0;
+          if (res_lds >= 0) t += lds[res_lds + (colc >> 4) * PCS + (colc & 15)];
+          const float ot = ldc(&o.v_act) == ACT_GELU ? 0.5f * t * (1.0f + sbm_erf(t * 0.70710678118654752440f)) : t;      // (eligibility: GELU or none)
+          if (own) {
+            lds[out_lds + pix_at(col, 0)] = ot;
+            if (ldc(&o.out_g)) ldc(&o.out_g)[(long long)b * ldc(&o.v_ldo) + col] = ot;
+            ov = ot;
+          }
+        } else if (kd == PIX_DW1) {
+          // depth-wise 7x7 at one position = its centre tap (unet_model.py:115 at 1x1; SURVEY appendix A "degenerate sizes")
+          const int C = ldc(&o.dw.C);
+          if (tid < C) {
+            const float a = fmaf(lds[ldc(&o.in_lds) + pix_at(tid, 0)], pe0, 0.f);
+            ov = a + (pe1 + pe2);
+            lds[out_lds + pix_at(tid, 0)] = ov;
+            if (ldc(&o.out_g)) ldc(&o.dw.out)[(long long)b * ldc(&o.dw.ldo) + tid] = ov;
+          }
+        } else {
+          // GroupNorm(1, C)(u) + x at one position (LinearAttention tail + Residual, unet_model.py:173-175, 21-27)
+          float su, sq;
+          stat_sum(ldc(&o.gn_stat), &su, &sq);
+          const float inv_count = ldc(&o.gr.inv_count);
+          const double mean_d = (double)su * (double)inv_count;
+          double var = (double)sq * (double)inv_count - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
+          const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + 1e-5));
+          const int C = ldc(&o.gr.C);
+          if (tid < C) {
+            const float u = lds[ldc(&o.in_lds) + pix_at(tid, 0)], x = lds[ldc(&o.x_lds) + pix_at(tid, 0)];
+            const float y = ((u - mean) * rstd) * pe0 + pe1 + x;
+            lds[out_lds + pix_at(tid, 0)] = y;
+            if (ldc(&o.out_g)) ldc(&o.gr.out)[(long long)b * ldc(&o.gr.ldo) + tid] = y;
+          }
+        }
+        if (j + 1 < run) PIX_REQUEST_SMALL(ops[k + j + 1]);
+        if (so >= 0) {
+          const float sacc = wave_sum(ov), qacc = wave_sum(ov * ov);
+          if (lane == 0) { stat[(so * PNW + wave) * 2] = sacc; stat[(so * PNW + wave) * 2 + 1] = qacc; }
+        }
+        __syncthreads();
+        if (ldc(&o.stat_g)) {                               // the plan's partial layouts (debug sub-ranges only): one (sum, sumsq) per 32-column block of a
+          if (tid == 0) {                                   // GEMM's output, one per pixel for the depth-wise op
+            float su, sq;
+            stat_sum(so, &su, &sq);
+            float2* dst = kd == PIX_VEC ? ldc(&o.stat_g) : ldc(&o.dw.stat);
+            if (kd == PIX_VEC) {
+              const int nstore = ldc(&o.v_nstore), nblk = (nstore + 31) >> 5;
+              for (int bk = 0; bk < nblk; ++bk) {
+                float s32 = 0.f, q32 = 0.f;
+                for (int c = bk * 32; c < bk * 32 + 32 && c < nstore; ++c) { const float v = lds[out_lds + pix_at(c, 0)]; s32 += v; q32 += v * v; }
+                dst[(long long)bk * B + b] = make_float2(s32, q32);
+              }
+            } else {
+              dst[b] = make_float2(su, sq);
+            }
+          }
+        }
+      }
+      k += run - 1;
       continue;
     }
     // ---------------------------------------------------------------- GEMM: everything comes from the item table
@@ -512,33 +740,43 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       f32x4p acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const int nu = ldc(&pc->nkp) / PD;
       if (!small) {
+        // Both waves of a SIMD run this loop and share its matrix pipe; they fall into lock-step (same code, fair arbitration), so whatever a
+        // wave does BETWEEN two MFMA blocks is pipe idle time for both (round 4: the loop ran at 80 % of the MFMA issue rate with or without its
+        // weight loads, tools/build_variant.sh noload).  Hence every LDS read is REQUESTED in front of a block and CONSUMED behind it -- the A
+        // operands of step i + 1, the row selector of step i + 2 -- and the gap holds only the ring loads and a few address operations; the
+        // source-2 scaling (GroupNorm-folded ops with a fused residual conv) is a separate instantiation.
         const int g = lane >> 4;
         const int n = (((wave >> ldc(&pc->gshift)) & ((1 << ldc(&pc->rshift)) - 1)) + ldc(&pc->rg0)) * 16 + (lane & 15);     // this lane's output row: row group of the wave's unit x 16 + lane
-        int rs = rtab[((asel[0] >> 16) & 0x7fff) * 16 + n];
-        const float* ap0 = lds + (asel[0] & 0xffff) + rs * 16 + 4 * g;
-        f32x4p a0 = *reinterpret_cast<const f32x4p*>(ap0), a1 = *reinterpret_cast<const f32x4p*>(ap0 + PCS);
-        if (scale2 && (asel[0] >> 31)) { a0 *= inv_r; a1 *= inv_r; }
-        rs = rtab[((asel[1] >> 16) & 0x7fff) * 16 + n];
-        for (int u = 0; u < nu; ++u) {
-          const bool last = u == nu - 1;
-          const PixStep* lst = last ? st_n : st_c + (u + 1) * PD;
-          const unsigned loff = last ? off_n : off_c;
+        auto kloop16 = [&](auto sc_tag) {
+          constexpr bool SC = decltype(sc_tag)::value;
+          int rs = rtab[((asel[0] >> 16) & 0x7fff) * 16 + n];
+          const float* ap0 = lds + (asel[0] & 0xffff) + rs * 16 + 4 * g;
+          f32x4p a0 = *reinterpret_cast<const f32x4p*>(ap0), a1 = *reinterpret_cast<const f32x4p*>(ap0 + PCS);
+          if (SC && (asel[0] >> 31)) { a0 *= inv_r; a1 *= inv_r; }
+          rs = rtab[((asel[1] >> 16) & 0x7fff) * 16 + n];
+          const float* apn = lds + (asel[1] & 0xffff) + rs * 16 + 4 * g;      // A operands of the NEXT step
+          for (int u = 0; u < nu; ++u) {
+            const bool last = u == nu - 1;
+            const PixStep* lst = last ? st_n : st_c + (u + 1) * PD;
+            const unsigned loff = last ? off_n : off_c;
 #pragma unroll
-          for (int r = 0; r < PD; ++r) {
-            // A operands of the NEXT step (its row was selected one step ago), row selector of the step after it
-            const unsigned an = asel[(r + 1) % PD];
-            const float* apn = lds + (an & 0xffff) + rs * 16 + 4 * g;
-            f32x4p n0 = *reinterpret_cast<const f32x4p*>(apn), n1 = *reinterpret_cast<const f32x4p*>(apn + PCS);
-            if (scale2 && (an >> 31)) { n0 *= inv_r; n1 *= inv_r; }
-            const PixStep e = ldc_step(lst + r);
-            PIX_MFMA16_SLOT(r, a0, a1);
-            asel[r] = e.a_sel;
-            rs = rtab[((asel[(r + 2) % PD] >> 16) & 0x7fff) * 16 + n];
-            const float* base_ = frag + e.w_off;
-            PIX_LOAD_SLOT(r, base_, loff);
-            a0 = n0; a1 = n1;
+            for (int r = 0; r < PD; ++r) {
+              // requested here, used behind the MFMA block: next step's A operands, the row selector of the step after it, this slot's next table entry
+              const f32x4p n0 = *reinterpret_cast<const f32x4p*>(apn), n1 = *reinterpret_cast<const f32x4p*>(apn + PCS);
+              const unsigned an = asel[(r + 1) % PD], an2 = asel[(r + 2) % PD];
+              const int rs2 = rtab[((an2 >> 16) & 0x7fff) * 16 + n];
+              const PixStep e = ldc_step(lst + r);
+              PIX_MFMA16_SLOT(r, a0, a1);
+              asel[r] = e.a_sel;
+              const float* base_ = frag + e.w_off;
+              PIX_KLOAD_SLOT(r, base_, loff);
+              apn = lds + (an2 & 0xffff) + rs2 * 16 + 4 * g;
+              if (SC) { const float f = (an >> 31) ? inv_r : 1.0f; a0 = n0 * f; a1 = n1 * f; }
+              else { a0 = n0; a1 = n1; }
+            }
           }
-        }
+        };
+        if (scale2) kloop16(std::true_type{}); else kloop16(std::false_type{});
       } else {
         const int ri = lane & 3;
         int rs = rtab[((asel[0] >> 16) & 0x7fff) * 16 + ri];
@@ -561,7 +799,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             asel[r] = e.a_sel;
             rs = rtab[((asel[(r + 2) % PD] >> 16) & 0x7fff) * 16 + ri];
             const float* base_ = frag + e.w_off;
-            PIX_LOAD_SLOT(r, base_, loff);
+            PIX_KLOAD_SLOT(r, base_, loff);
             q0 = n0; q1 = n1; q2 = n2; q3 = n3;
           }
         }
@@ -595,6 +833,9 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         float sacc = 0.f, qacc = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+          // the epilogue is VALU-issue-bound (two waves per SIMD, four cycles per instruction): a wave none of whose lanes owns a quad j of
+          // this pass -- every pass of fewer than 1024 / 512 output quads -- skips the whole block instead of executing it masked
+          if (wave * 64 + j * PNT >= q.total) continue;
           const int row = q.row[j], col = q.col[j];
           const int cw = col - grp0 * gw, grp = small ? cw >> 6 : cw >> 5, sub = cw & (gw - 1);
           const int unit = ((q.prow[j] >> 4) << gshift) | grp;       // the wave (of K slice 0) that owns this output: [column group | row group]
@@ -609,11 +850,8 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             if (act == ACT_GELU) {                        // the one activation of the ConvNeXt blocks: packed, the switch outside the element loop
               const sbm_f32x2 g0 = sbm_gelu2((sbm_f32x2){t[0], t[1]}), g1 = sbm_gelu2((sbm_f32x2){t[2], t[3]});
               o[0] = g0.x; o[1] = g0.y; o[2] = g1.x; o[3] = g1.y;
-            } else if (act == ACT_NONE) {
+            } else {                                       // ACT_NONE: the only other activation a Unet op has (pix_gemm_supported)
               o = t;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = pix_act(act, t[e]);
             }
             if (out_lds >= 0) *reinterpret_cast<f32x4p*>(lds + out_lds + pix_at2(col, row, out_sub)) = o;
             if (out_g) *reinterpret_cast<f32x4p*>(out_g + ((long long)row * B + b) * ldo + col) = o;
@@ -658,6 +896,7 @@ struct PFragOp {                          // fragment-order copy of one GEMM op'
   int groups = 0;                         // column groups (32 or 64 columns)
   std::vector<int> taps;                  // live taps (ky * KW + kx), in step order
   int ndc = 0, ndc2 = 0;                  // K steps per tap / of source 2
+  bool vec = false; int sshift = 0;       // PIX_VEC packing: [step][thread = column << sshift | slice][4], F = steps of 8 KB (ndc per tap, ndc2 of source 2)
 };
 
 struct PProgram { PixOpD* d_ops = nullptr; PixItem* d_items = nullptr; PixStep* d_steps = nullptr; unsigned short* d_rowtab = nullptr;
@@ -671,6 +910,7 @@ struct PixState {
   std::map<long long, PProgram> programs; // by first * 4096 + count
   std::mutex mu;                          // programs are built on demand (debug sub-ranges); one handle may be driven from several host threads in the tests
   const float* zero4 = nullptr;           // zeros, as many as the widest op has columns (tail of the fragment arena)
+  long long zero_blk = 0;                 // float offset of an 8 KB block of zeros (padding steps of the one-position runs' weight stream)
 };
 
 namespace {
@@ -687,6 +927,7 @@ const char* pix_gemm_supported(const GemmOp& g) {
   if ((P_out > 16 && P_out != 64) || (P_in > 16 && P_in != 64) || g.a_ext || g.out_nchw || g.w_pix_stride || g.bias_pix_stride || g.a_bcast || g.a_rows) return "pixel kernel: unsupported GEMM op";
   if (P_out == 64 && (g.up2 != 1 || (g.has_res && g.r.H * g.r.W != 64) || (g.has2 && g.a2.H * g.a2.W != 64))) return "pixel kernel: a 64-pixel output takes its residual / source 2 at its own resolution only";
   if ((g.Kp & 31) || (g.has2 && (g.Kp2 & 31)) || (g.Npad & 31) || (g.out.C & 3)) return "pixel kernel: K and N must be multiples of 32";
+  if (g.act != ACT_NONE && g.act != ACT_GELU) return "pixel kernel: activations other than GELU are not built in (no Unet op has one)";
   if (g.has2 && g.a2.H * g.a2.W > 16 && g.a2.H * g.a2.W != 64) return "pixel kernel: source 2 has an unsupported pixel count";
   return nullptr;
 }
@@ -727,6 +968,42 @@ void pack_fragments(const float* prm, const GemmOp& g, PFragOp* fo, std::vector<
     }
 }
 
+// One output pixel, a power-of-two width that fills the 512 threads with at most 8 K slices per column: the vector-ALU mat-vec (PIX_VEC).
+bool pix_vec_on() { static const bool on = !(std::getenv("SBM_PIX_VEC") && std::atoi(std::getenv("SBM_PIX_VEC")) == 0); return on; }
+bool pix_vec_eligible(const GemmOp& g) {
+  if (!pix_vec_on() || g.Hout * g.Wout != 1 || g.a.H * g.a.W > 16) return false;
+  if (g.Npad != 64 && g.Npad != 128 && g.Npad != 256 && g.Npad != 512) return false;
+  if (g.act != ACT_NONE && g.act != ACT_GELU) return false;
+  if (g.has2 && g.a2.H * g.a2.W != 1) return false;
+  if (g.has_res && g.r.H * g.r.W != 1) return false;
+  return true;
+}
+// [tap][Npad][Kp] (+ [Npad][Kp2]) -> [step][thread][4]: step = (live tap, 4 S consecutive k), thread = (column n, slice s) holds W[n][k0 + 4 s .. + 3]
+void pack_vec(const float* prm, const GemmOp& g, PFragOp* fo, std::vector<float>* arena) {
+  fo->vec = true; fo->small = true;
+  int sh = 0; while ((g.Npad << sh) < PNT) ++sh;
+  fo->sshift = sh;
+  const int S = 1 << sh, kstep = 4 * S;
+  fo->ndc = g.Kp / kstep; fo->ndc2 = g.has2 ? g.Kp2 / kstep : 0;
+  fo->taps.clear();
+  for (int ky = 0; ky < g.KH; ++ky) for (int kx = 0; kx < g.KW; ++kx) if (pix_tap_live(g, ky, kx)) fo->taps.push_back(ky * g.KW + kx);
+  fo->F = (int)fo->taps.size() * fo->ndc + fo->ndc2;
+  fo->groups = 1;
+  fo->off = (long long)arena->size();
+  arena->resize(arena->size() + (size_t)((fo->F + 15) / 16 * 16) * PNT * 4, 0.f);      // padded with zero steps to whole rounds of the ring (4 slots of 4 steps)
+  float* dst = arena->data() + fo->off;
+  for (int f = 0; f < fo->F; ++f) {
+    const bool s2 = f >= (int)fo->taps.size() * fo->ndc;
+    const int tap = s2 ? 0 : fo->taps[f / fo->ndc], dc = s2 ? f - (int)fo->taps.size() * fo->ndc : f % fo->ndc;
+    const float* W = s2 ? prm + g.w2_off : prm + g.w_off + (long long)tap * g.Npad * g.Kp;
+    const int Kp = s2 ? g.Kp2 : g.Kp;
+    for (int t = 0; t < PNT; ++t) {
+      const int n = t >> sh, k = dc * kstep + 4 * (t & (S - 1));
+      std::memcpy(dst + ((size_t)f * PNT + t) * 4, W + (long long)n * Kp + k, 16);
+    }
+  }
+}
+
 struct PBuilder {
   const Plan& plan; const DevPlan& dp; const PixState& st; int first, count;
   std::vector<PSlot> slots; int act_chunks = 0;
@@ -736,6 +1013,27 @@ struct PBuilder {
   const std::vector<PSlot>* preset = nullptr;
   std::vector<int> touched;
   const char* err = nullptr;
+  int run_first = -1, run_stream = -1, run_slots = 0;   // one-position run being assembled: its first program op, the step index of its slot table, its slots
+
+  static bool run_kind(int kind) { return kind == PIX_VEC || kind == PIX_DW1 || kind == PIX_GNR1; }
+  void flush_run() {
+    if (run_first < 0) return;
+    ops[run_first].v_stream = run_stream >= 0 ? run_stream : 0;
+    ops[run_first].v_slots = run_slots;
+    // word 1 of a slot's entry: the weight offset of the slot FOUR further down the stream -- what the consumer of this slot requests next
+    for (int sidx = 0; sidx + PD < run_slots; ++sidx) steps[run_stream + 4 * sidx].a_sel = steps[run_stream + 4 * (sidx + PD)].w_off;
+    run_first = -1; run_stream = -1; run_slots = 0;
+  }
+  void push_op(const PixOpD& d) {
+    if (run_kind(d.kind)) {
+      if (run_first < 0) { run_first = (int)ops.size(); ops.push_back(d); ops.back().v_run = 1; }
+      else { ops.push_back(d); ops[run_first].v_run += 1; }
+      if (d.kind == PIX_VEC) { if (run_stream < 0) run_stream = d.v_step_base; run_slots += d.v_n1; }
+    } else {
+      flush_run();
+      ops.push_back(d);
+    }
+  }
 
   static int chunks_of(int ld) { return (ld + 15) / 16 + 1; }     // + one chunk of slack: K is walked to the weights' padded depth
   static int nsub_of(int P) { return P > 16 ? 4 : 1; }
@@ -784,9 +1082,33 @@ struct PBuilder {
   }
   // An op that writes only PART of a buffer (one half of a skip concatenation) while the rest was produced outside the run: the whole
   // buffer is staged first, so that later readers of the full width find the other half.
-  void mark_produced(const View& v) {
+  // The views op `o` reads / writes, for rest_filled_in_run
+  static void op_views(const Op& o, std::vector<const View*>* rd, std::vector<const View*>* wr) {
+    if (o.kind == OP_GEMM) { rd->push_back(&o.g.a); if (o.g.has2) rd->push_back(&o.g.a2); if (o.g.has_res) rd->push_back(&o.g.r); wr->push_back(&o.g.out); }
+    else if (o.kind == OP_DWCONV7) { rd->push_back(&o.dw.in); wr->push_back(&o.dw.out); }
+    else if (o.kind == OP_GN_RES) { rd->push_back(&o.gr.u); rd->push_back(&o.gr.x); wr->push_back(&o.gr.out); }
+    else if (o.kind == OP_LINATTN || o.kind == OP_ATTN) { rd->push_back(&o.at.qkv); wr->push_back(&o.at.out); }
+  }
+  // Op `cur` writes the channels [v.off, v.off + v.C) of slot si and nothing of the slot has been produced yet.  True when every channel of
+  // the slot OUTSIDE that range is written by a later op of this run before any op of the run reads it (the two halves of a skip
+  // concatenation: the down path stores its half, the up path's producer fills the other half before the concatenation is read) -- then
+  // the buffer need not be staged from the workspace first.
+  bool rest_filled_in_run(int si, const View& v, int cur) const {
+    const PSlot& sl = slots[si];
+    std::vector<char> have(sl.ld, 0);
+    auto inside = [&](const View& w) { return w.ld == sl.ld && w.H * w.W == sl.P && w.off >= sl.base && w.off < sl.base + sl.ld; };
+    for (int c = 0; c < v.C; ++c) have[(int)(v.off - sl.base) + c] = 1;
+    for (int j = cur + 1; j < first + count; ++j) {
+      std::vector<const View*> rd, wr;
+      op_views(plan.ops[j], &rd, &wr);
+      for (const View* r : rd) if (inside(*r)) for (int c = 0; c < r->C; ++c) if (!have[(int)(r->off - sl.base) + c]) return false;
+      for (const View* w : wr) if (inside(*w)) for (int c = 0; c < w->C; ++c) have[(int)(w->off - sl.base) + c] = 1;
+    }
+    return true;     // nothing in the run reads the rest before it is written (readers outside the run take the workspace copy, which every writer keeps current)
+  }
+  void mark_produced(const View& v, int cur = -1) {
     int si; slab(v, &si);
-    if (!produced.count(si) && (v.off != slots[si].base || v.C < slots[si].ld)) ops.push_back(stage_op(slots[si]));
+    if (!produced.count(si) && (v.off != slots[si].base || v.C < slots[si].ld) && !(cur >= 0 && rest_filled_in_run(si, v, cur))) push_op(stage_op(slots[si]));
     produced[si] = 1;
   }
   int stat_slot(long long off) {
@@ -805,7 +1127,7 @@ struct PBuilder {
     if (stat_off >= 0 && !stat_of.count(stat_off)) {
       d.st_stat = stat_slot(stat_off); d.st_part = reinterpret_cast<const float2*>(dp.ws + stat_off); d.st_nparts = nparts;
     }
-    ops.push_back(d);
+    push_op(d);
     produced[si] = 1;
     return off;
   }
@@ -834,23 +1156,25 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         const DwOp& o = op.dw;
         if (((o.in.H > 4 || o.in.W > 4) && !(o.in.H == 8 && o.in.W == 8 && 49 * o.in.C <= P_SCR_F && (o.in.C & 3) == 0)) || o.stat_slabs > 1) return "pixel kernel: depth-wise op outside the supported shapes";
         d.in_lds = b.need(o.in); d.in_sub = PBuilder::sub_floats(o.in.ld);
-        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out); d.out_sub = PBuilder::sub_floats(o.out.ld);
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out, i); d.out_sub = PBuilder::sub_floats(o.out.ld);
         d.dw = make_dw_args(plan, o, dp.prm, dp.ws, dp.ctl);
         if (o.stat_off >= 0) d.stat_out = b.stat_slot(o.stat_off);
+        if (pix_vec_on() && o.in.H == 1 && o.in.W == 1 && o.in.C <= PNT) d.kind = PIX_DW1;
       } else if (op.kind == OP_GN_RES) {
         const GnResOp& o = op.gr;
         if ((o.u.H * o.u.W > 16 && o.u.H * o.u.W != 64) || o.out_ext || (o.u.C & 3)) return "pixel kernel: unsupported GroupNorm+residual op";
         d.in_lds = b.need(o.u, o.part_off, o.nparts); d.in_sub = PBuilder::sub_floats(o.u.ld);
         d.x_lds = b.need(o.x); d.x_sub = PBuilder::sub_floats(o.x.ld);
         d.gn_stat = b.stat_slot(o.part_off);
-        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out); d.out_sub = PBuilder::sub_floats(o.out.ld);
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out, i); d.out_sub = PBuilder::sub_floats(o.out.ld);
         d.gr = make_gnres_args(o, dp.prm, dp.ws);
+        if (pix_vec_on() && o.u.H * o.u.W == 1 && o.u.C <= PNT) d.kind = PIX_GNR1;
       } else if (op.kind == OP_LINATTN) {
         const AttnOp& o = op.at;
         { const int np = o.qkv.H * o.qkv.W;
           if ((np != 16 && np != 4) || o.dh != 32 || o.heads * 32 > 256 || o.heads * 32 * 33 > P_SCR_F || np * o.heads > 256) return "pixel kernel: unsupported attention op"; }
         d.in_lds = b.need(o.qkv);
-        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out);
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out, i);
         d.at = make_attn_args(o, dp.ws);
       } else if (op.kind == OP_GEMM) {
         const GemmOp& g = op.g;
@@ -862,6 +1186,37 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         const int a_lds = b.need(g.a, g.gn ? g.gn_part_off : -1, g.gn_nparts);
         int a2_lds = -1;
         if (g.has2) a2_lds = b.need(g.a2);
+        if (fo.vec) {                                        // one output pixel: the vector-ALU mat-vec
+          d.kind = PIX_VEC;
+          d.v_res_lds = -1;
+          if (g.has_res) d.v_res_lds = b.need(g.r);
+          d.v_sshift = fo.sshift; d.v_Npad = g.Npad; d.v_nstore = g.out.C; d.v_act = g.act; d.v_ldo = g.out.ld;
+          d.v_bias = g.bias_off >= 0 ? dp.prm + g.bias_off : st.zero4; d.v_gn_s = d.v_gn_b1 = st.zero4;
+          if (g.gn) { d.v_gn = 1; d.gn_stat = b.stat_slot(g.gn_part_off); d.v_gn_inv = g.gn_inv_count; d.v_gn_s = dp.prm + g.gn_s_off; d.v_gn_b1 = dp.prm + g.gn_b1_off; }
+          d.out_g = dp.ws + g.out.off;
+          d.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out, i);
+          if (g.stat_off >= 0) { d.stat_out = b.stat_slot(g.stat_off); d.stat_g = reinterpret_cast<float2*>(dp.ws + g.stat_off); }
+          const int S = 1 << fo.sshift, kstep = 4 * S, n1 = (int)fo.taps.size() * fo.ndc;
+          d.v_step_base = (int)b.steps.size(); d.v_n2 = fo.ndc2;
+          std::vector<unsigned> asels;                       // the op's activation selectors in step order, padded to whole rounds of the ring
+          for (int f = 0; f < fo.F; ++f) {
+            const bool s2 = f >= n1;
+            const int ti = s2 ? 0 : f / fo.ndc, dc = s2 ? f - n1 : f % fo.ndc, k0 = dc * kstep;
+            int q = 0;
+            if (!s2) { const int tp = fo.taps[ti]; q = tap_source_pixel(0, 0, tp / g.KW, tp % g.KW, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W); if (q < 0) return "pixel kernel: a packed tap of a one-pixel op is dead"; }
+            asels.push_back((unsigned)((s2 ? a2_lds : a_lds) + q * 16 + (k0 >> 4) * PCS + (k0 & 15)) | (s2 && g.gn ? 0x80000000u : 0u));
+          }
+          const int padded = (fo.F + 15) / 16 * 16;
+          while ((int)asels.size() < padded) asels.push_back((unsigned)a_lds);       // zero weights: any readable activation
+          for (int s0 = 0; s0 < padded; s0 += 4) {           // one slot = 8 words = 4 table entries: {weight offset, -} {-, -} {sel 0, sel 1} {sel 2, sel 3}
+            b.steps.push_back(PixStep{(unsigned)(fo.off + (long long)s0 * PNT * 4), 0u});
+            b.steps.push_back(PixStep{0u, 0u});
+            b.steps.push_back(PixStep{asels[s0], asels[s0 + 1]});
+            b.steps.push_back(PixStep{asels[s0 + 2], asels[s0 + 3]});
+          }
+          d.v_n1 = padded / 4;
+          item_first = b.items.size();
+        } else {
         PixItem proto{};                                    // the fields every pass of this op shares
         proto.res_lds = -1;
         if (g.has_res) { proto.res_lds = b.need(g.r); proto.res_sub = PBuilder::sub_floats(g.r.ld); }
@@ -873,7 +1228,7 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         if (g.gn && g.has2) proto.flags |= PIF_SCALE2;
         if (fo.small) proto.flags |= PIF_SMALL;
         proto.out_g = dp.ws + g.out.off;
-        proto.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out);
+        proto.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out, i);
         d.out_g = proto.out_g;
         if (g.stat_off >= 0) { proto.stat_out = b.stat_slot(g.stat_off); proto.stat_g = reinterpret_cast<float2*>(dp.ws + g.stat_off); d.stat_g = proto.stat_g; }
         // row tables: one per live tap (+ source 2), 16 or 64 output rows
@@ -932,6 +1287,7 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         }
         d.nitems = (int)b.items.size() - (int)item_first;
         b.items[item_first].flags |= PIF_FIRST; b.items.back().flags |= PIF_LAST;
+        }
       } else {
         return "pixel kernel: op kind not supported";
       }
@@ -966,8 +1322,9 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
       }
       if (b.err) return b.err;
       for (int si : b.touched) b.slots[si].t1 = std::max(b.slots[si].t1, (int)b.ops.size());
-      b.ops.push_back(d);
+      b.push_op(d);
     }
+    b.flush_run();
     return nullptr;
   };
   PBuilder b0{plan, dp, st, first, count};
@@ -1008,7 +1365,8 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
   if (act_floats > 0xffff) return "pixel kernel: the activations exceed the step table's LDS range";
   if (pix_lds_bytes(act_floats, (int)b.rowtab.size() / 16) > 160 * 1024) return "pixel kernel: the activations do not fit the LDS";
   if (b.items.empty()) {                                   // a run without a GEMM still needs one (never consumed) item for the loader's prologue
-    PixItem it{}; it.step_base = 0; it.nkp = PD; it.grp_stride = 0; it.P_out = 1; it.Npad = 32; it.bias = it.gn_s = it.gn_b1 = st.zero4;
+    PixItem it{}; it.step_base = (int)b.steps.size(); it.nkp = PD; it.grp_stride = 0; it.P_out = 1; it.Npad = 32; it.bias = it.gn_s = it.gn_b1 = st.zero4;
+    // (step_base is not 0: a one-position run may have put its slot table at the front of the step array)
     b.items.push_back(it);
     for (int j = 0; j < PNW * PD; ++j) b.steps.push_back(PixStep{0u, 0u});
   }
@@ -1051,9 +1409,12 @@ const char* pixrun_prepare(DevPlan& dp, const float* host_params, double* frag_m
     const Op& op = plan.ops[i];
     if (!op.chain || op.time_path || op.kind != OP_GEMM) continue;
     if (const char* e = pix_gemm_supported(op.g)) { delete st; return e; }
-    pack_fragments(host_params, op.g, &st->fops[i], &arena);
+    if (pix_vec_eligible(op.g)) pack_vec(host_params, op.g, &st->fops[i], &arena);
+    else pack_fragments(host_params, op.g, &st->fops[i], &arena);
     max_npad = std::max(max_npad, op.g.Npad);
   }
+  st->zero_blk = (long long)arena.size();                  // 8 KB of zeros: the padding steps of the one-position runs
+  arena.resize(arena.size() + (size_t)PNT * 4, 0.f);
   const size_t zero_off = arena.size();                    // a zero VECTOR as long as the widest op: absent bias / GroupNorm tables are read at any column
   arena.resize(arena.size() + (size_t)max_npad + 64, 0.f);
   if (frag_mb) *frag_mb = arena.size() * 4.0 / 1e6;

@@ -290,6 +290,13 @@ class Builder {
     return v;
   }
   void free_act(const View& v) { ws_free(v.off); }
+  // a score net's converted input: pinned, because the sampler's update kernels keep it current BETWEEN forwards (sampler.hip store_pbc) --
+  // nothing else may recycle the block, and its zero padding channels must stay zero
+  View new_input_act(int H, int W, int C) {
+    View v; v.H = H; v.W = W; v.C = pad8(C); v.ld = v.C;
+    v.off = ws_alloc((int64_t)H * W * B * v.ld, true);
+    return v;
+  }
   int64_t new_stats(int nparts, bool pin = false) { return ws_alloc((int64_t)nparts * B * 2, pin); }
   int chain_pix = 0;        // ops with P <= chain_pix are marked for the chain kernel
   bool pix_mode = false;    // the marked ops are meant for the sample-owned pixel kernel (pixrun.hip) instead of the chain kernel
@@ -312,7 +319,12 @@ class Builder {
   static long splitk_max_tiles() { static const long v = getenv("SBM_SPLITK_TILES") ? atol(getenv("SBM_SPLITK_TILES")) : 384; return v; }
   static long splitk_target() { static const long v = getenv("SBM_SPLITK_TARGET") ? atol(getenv("SBM_SPLITK_TARGET")) : 512; return v; }
   static int splitk_min_chunks() { static const int v = getenv("SBM_SPLITK_MINCH") ? atoi(getenv("SBM_SPLITK_MINCH")) : 6; return v; }
+  // SBM_SPLITK_BALANCE=<min chunks> (experiment): grids of one to two workgroup waves (384 .. 767 tiles: every CU gets its two resident workgroups
+  // and the launch lasts as long as the CU with the two longest tiles) are cut in K halves, so that the hardware dispatcher deals ~4 units per
+  // CU in arrival order
+  static int splitk_balance_min() { static const int v = getenv("SBM_SPLITK_BALANCE") ? atoi(getenv("SBM_SPLITK_BALANCE")) : 0; return v; }
   static int splitk_for(long tiles, int min_chunks) {
+    if (splitk_enabled() && splitk_balance_min() > 0 && tiles >= splitk_max_tiles() && tiles < 768 && min_chunks >= splitk_balance_min()) return 2;
     if (!splitk_enabled() || tiles >= splitk_max_tiles()) return 1;
     const long S = std::min<long>(std::min<long>((splitk_target() + tiles - 1) / tiles, min_chunks / splitk_min_chunks()), 16);
     return S >= 2 ? (int)S : 1;
@@ -700,7 +712,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
     plan->needs_time = d.td ? 1 : 0;
 
     // external NCHW input -> PBC
-    View xin = b.new_act(Hp, Wp, cfg.channels);
+    View xin = b.new_input_act(Hp, Wp, cfg.channels);
     { Op& op = b.push(OP_NCHW_TO_PBC, "input"); op.cv.B = B; op.cv.C = cfg.channels; op.cv.Hn = cfg.H; op.cv.Wn = cfg.W; op.cv.pad_y = pad_y; op.cv.pad_x = pad_x; op.cv.out = xin; }
 
     // time path: sinusoid -> Linear -> GELU -> Linear (-> GELU, shared first op of every block mlp) -> all block Linears
@@ -779,7 +791,7 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       Op& cv = plan->ops[0];                                   // the input conversion emitted above
       View rows; rows.H = Hp; rows.W = 1; rows.C = Wp * 8; rows.ld = rowK;
       b.free_act(xin);
-      rows.off = b.ws_alloc((int64_t)Hp * B * rows.ld);
+      rows.off = b.ws_alloc((int64_t)Hp * B * rows.ld, true);     // pinned: the sampler's update kernels keep it current between forwards (sampler.hip store_pbc), so nothing else may recycle it
       cv.cv.out = rows; cv.cv.rowpack = 1; cv.cv.Wo = Wp; cv.cv.Cpad = 8;
       xin = rows;
       const float* w = b.T("init_conv.weight", (int64_t)d.init_dim * cfg.channels * 49); const float* bi = b.T("init_conv.bias", d.init_dim);
@@ -1086,7 +1098,7 @@ bool build_unet_oa_plan(const UnetOACfg& cfg, int B, int with_z, const float* co
     plan->needs_time = 1;
     for (int v : {mc}) if (v % 32) throw std::runtime_error("plan: UNetModel channel counts must be multiples of 32 (GroupNorm32)");
 
-    View xin = b.new_act(cfg.H, cfg.W, cfg.in_channels);
+    View xin = b.new_input_act(cfg.H, cfg.W, cfg.in_channels);
     { Op& op = b.push(OP_NCHW_TO_PBC, "input"); op.cv.B = B; op.cv.C = cfg.in_channels; op.cv.Hn = cfg.H; op.cv.Wn = cfg.W; op.cv.out = xin; }
 
     // ---- emb = time_embed(timestep_embedding(t)) [+ proj(z)]; every ResBlock starts its emb path with SiLU ----

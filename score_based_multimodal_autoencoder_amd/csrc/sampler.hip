@@ -62,12 +62,33 @@ __device__ __forceinline__ Coef sde_coef(const SdeParams& s, float t) {
   return c;
 }
 
+// the new state in the score net's input layout: element e = (c, y, x .. x + 3) of sample b (W % 4 == 0, no spatial padding)
+__device__ __forceinline__ void store_pbc(const StepArgs& a, int b, int e, const float4 o) {
+  const int HW = a.pbc_H * a.pbc_W, c = e / HW, r = e - c * HW, y = r / a.pbc_W, x = r - y * a.pbc_W;
+  if (a.pbc_rowpack) {                     // one "pixel" per image row, channel x * Cv + c (plan.h CvtOp::rowpack)
+    float* d = a.pbc_out + ((long long)y * a.B + b) * a.pbc_ld + x * a.pbc_Cv + c;
+    d[0] = o.x; d[a.pbc_Cv] = o.y; d[2 * a.pbc_Cv] = o.z; d[3 * a.pbc_Cv] = o.w;
+  } else {
+    float* d = a.pbc_out + ((long long)(y * a.pbc_W + x) * a.B + b) * a.pbc_ld + c;
+    const long long ps = (long long)a.B * a.pbc_ld;
+    d[0] = o.x; d[ps] = o.y; d[2 * ps] = o.z; d[3 * ps] = o.w;
+  }
+}
+// Every workgroup of the launch has read the step counter when it arrives here; the last one to arrive moves it on and re-arms the ticket.
+__device__ __forceinline__ void advance_by_last_workgroup(const StepArgs& a, int stepi) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(a.adv_ticket, 1u);
+    if (t == gridDim.x - 1) { *a.adv_ticket = 0u; *a.adv_counter = stepi + 1; }
+  }
+}
+
 __global__ __launch_bounds__(256) void em_step_kernel(const StepArgs a) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // one float4 per thread
   const int q4 = a.CHW >> 2;
-  if (idx >= (long long)a.B * q4) return;
-  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
   const int stepi = a.step_counter ? *a.step_counter : a.step_base;
+  if (idx >= (long long)a.B * q4) { if (a.adv_counter) advance_by_last_workgroup(a, stepi); return; }
+  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
   const float t = a.t ? a.t[b] : a.timesteps[stepi];
   const Coef c = sde_coef(a.sde, t);
   const float4 x = *reinterpret_cast<const float4*>(a.x + (long long)b * a.CHW + e);
@@ -83,6 +104,8 @@ __global__ __launch_bounds__(256) void em_step_kernel(const StepArgs a) {
 #undef SBM_EM
   *reinterpret_cast<float4*>(a.mean_out + (long long)b * a.CHW + e) = m;
   *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
+  if (a.pbc_out) store_pbc(a, b, e, o);
+  if (a.adv_counter) advance_by_last_workgroup(a, stepi);
 }
 
 // per-sample L2 norms of the score and of the corrector's noise: one workgroup per sample
@@ -120,9 +143,9 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(const StepArgs a) 
   }
   const long long idx = (long long)blockIdx.x * blockDim.x + tid;
   const int q4 = a.CHW >> 2;
-  if (idx >= (long long)a.B * q4) return;
-  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
   const int stepi = a.step_counter ? *a.step_counter : a.step_base;
+  if (idx >= (long long)a.B * q4) { if (a.adv_counter) advance_by_last_workgroup(a, stepi); return; }
+  const int b = (int)(idx / q4), e = (int)(idx - (long long)b * q4) * 4;
   const float t = a.t ? a.t[b] : a.timesteps[stepi];
   float alpha = 1.0f;
   if (a.sde.kind != 2) {                                            // sde_helper2.py:56-60
@@ -141,6 +164,8 @@ __global__ __launch_bounds__(256) void langevin_update_kernel(const StepArgs a) 
   o.x = m.x + sq * z.x; o.y = m.y + sq * z.y; o.z = m.z + sq * z.z; o.w = m.w + sq * z.w;
   *reinterpret_cast<float4*>(a.mean_out + (long long)b * a.CHW + e) = m;
   *reinterpret_cast<float4*>(a.x_out + (long long)b * a.CHW + e) = o;
+  if (a.pbc_out) store_pbc(a, b, e, o);
+  if (a.adv_counter) advance_by_last_workgroup(a, stepi);
 }
 
 // Fixed-step Langevin update of the alternative samplers: x_out = x + mask_c * (a * score + b * noise) per modality

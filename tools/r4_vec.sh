@@ -1,0 +1,7 @@
+set -x
+export PYTHONUNBUFFERED=1
+O=gpurun_out/r04c; rm -rf $O; mkdir -p $O
+timeout -k 10 300 python tools/pix_opcheck.py P5 > $O/opcheck_P5.txt 2>&1; grep -c WRONG $O/opcheck_P5.txt; tail -5 $O/opcheck_P5.txt
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > $O/tests_parity.log 2>&1; tail -5 $O/tests_parity.log
+PIX_PHASES=1 timeout -k 10 200 python tools/pix_stamps.py > $O/stamps.txt 2>&1; grep total $O/stamps.txt
+timeout -k 10 300 python tools/ab_bench.py --reps 2 vec=default novec=env:SBM_PIX_VEC=0 > $O/ab.txt 2>&1; cat $O/ab.txt
