@@ -787,8 +787,7 @@ int sbm_fill_normal(float* out, long n_per_sample, int B, uint64_t seed, uint64_
 // The plan's input conversion op when the sampler's update kernels can write its output themselves (sampler.hip store_pbc): an unconditional
 // loop over a state without spatial padding and with rows of a multiple of four elements; -1 otherwise (the forward then converts as usual).
 static int sampler_cvt_op(const sbm_model* m, bool conditional) {
-  static const bool off = std::getenv("SBM_NO_FUSED_CVT") != nullptr;
-  if (conditional || off) return -1;
+  if (conditional || std::getenv("SBM_NO_FUSED_CVT")) return -1;
   const Plan& P = m->plan;
   for (int i = 0; i < (int)P.ops.size(); ++i) {
     if (P.ops[i].kind != OP_NCHW_TO_PBC) continue;

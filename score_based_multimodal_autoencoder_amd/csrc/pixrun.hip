@@ -624,11 +624,13 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
           // exhausted, with the next MFMA pass's first steps, which the ring held when the run began.  The activations are requested in front
           // of the wait.  Source-2 steps (bit 31: the fused 1x1 residual conv, which enters unnormalised) are scaled by 1 / rstd so that the
           // common GroupNorm scaling cancels, as on the MFMA path.
+          i32x8p e_cur = ldc_x8(sc);
           auto slots4 = [&](auto sc_tag) __attribute__((always_inline)) {
             constexpr bool SC = decltype(sc_tag)::value;
 #pragma unroll
             for (int r = 0; r < PD; ++r) {
-              const i32x8p e = ldc_x8(sc);
+              const i32x8p e = e_cur;
+              e_cur = ldc_x8(sc + 8);                        // the NEXT slot's entry: a table read asked for when it is needed costs a scalar-cache miss per slot
               f32x4p a[4];
 #pragma unroll
               for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4p*>(__builtin_assume_aligned(lds + ((unsigned)e[4 + i] & 0x7fffffffu) + aoff, 16));
@@ -716,13 +718,27 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       continue;
     }
     // ---------------------------------------------------------------- GEMM: everything comes from the item table
-#define PSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && ci < 96) dbg[128 + ci * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PSTAMP_AT(ph) do { if (dbg && b == 0 && tid == 0 && ci < 96) dbg[128 + ci * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+    // default: four phase stamps per pass (K loop | partial tiles + barrier | epilogue + barrier).  -DPIX_STAMP_EPI / -DPIX_STAMP_PRE (diagnostic
+    // builds, tools/build_variant.sh) move the four stamps INSIDE the epilogue / the pass prologue instead: PSTAMP_X(id)
+#if defined(PIX_STAMP_EPI)
+#define PSTAMP(ph) do { if ((ph) == 2) PSTAMP_AT(0); } while (0)
+#define PSTAMP_X(id) do { if ((id) >= 10 && (id) <= 12) PSTAMP_AT((id) - 9); } while (0)
+#elif defined(PIX_STAMP_PRE)
+#define PSTAMP(ph) do { if ((ph) == 0) PSTAMP_AT(3); } while (0)
+#define PSTAMP_X(id) do { if ((id) >= 0 && (id) <= 2) PSTAMP_AT(id); } while (0)
+#else
+#define PSTAMP(ph) PSTAMP_AT(ph)
+#define PSTAMP_X(id) do { } while (0)
+#endif
     const int g_nitems = ldc(&op.nitems);
     for (int it = 0; it < g_nitems; ++it) {
+      PSTAMP_X(0);
       const int ni = ci + 1 < nitems ? ci + 1 : 0;
       const PixItem* pn = items + ni;
       const unsigned off_n = lane_off(pn);
       const PixStep* st_n = slice_steps(pn);
+      PSTAMP_X(1);
       const int flags = ldc(&pc->flags);
       const bool small = (flags & PIF_SMALL) != 0, gn = (flags & PIF_GN) != 0, scale2 = (flags & PIF_SCALE2) != 0;
       float mean = 0.f, rstd = 1.f, inv_r = 1.f;
@@ -734,6 +750,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         double var = (double)sq * (double)ginv - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
         mean = (float)mean_d; rstd = rsqrtf((float)var + 1e-5f); inv_r = sqrtf((float)var + 1e-5f);
       }
+      PSTAMP_X(2);
       const int g_stat_out = ldc(&pc->stat_out);
       if ((flags & PIF_FIRST) && g_stat_out >= 0 && lane == 0) { stat[(g_stat_out * PNW + wave) * 2] = 0.f; stat[(g_stat_out * PNW + wave) * 2 + 1] = 0.f; }
       PSTAMP(0);
@@ -825,6 +842,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         PIX_EREAD4(eb[1], 116, 117, 118, 119); PIX_EREAD4(es[1], 120, 121, 122, 123); PIX_EREAD4(eg[1], 124, 125, 126, 127);
         const Quads q = q_cur;
         q_cur = request_epilogue_operands(pn);             // a[104 .. 127] are free again: the next pass's operands fly under this epilogue and its K loop
+        PSTAMP_X(10);
         const int gw = small ? 64 : 32, gshift = ldc(&pc->gshift), ushift = gshift + ldc(&pc->rshift), ksplit = 1 << ldc(&pc->kshift), grp0 = ldc(&pc->grp0);
         const int out_sub = ldc(&pc->out_sub), res_sub = ldc(&pc->res_sub), P_out = ldc(&pc->P_out);
         const int nstore = ldc(&pc->nstore), act = ldc(&pc->act), out_lds = ldc(&pc->out_lds), res_lds = ldc(&pc->res_lds), ldo = ldc(&pc->ldo);
@@ -865,11 +883,13 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             if ((tid & 7) == 0 && q.ok[j] && nbk < nblk) stat_g[((long long)row * nblk + nbk) * B + b] = make_float2(s32, q32);
           }
         }
+        PSTAMP_X(11);
         if (g_stat_out >= 0) {                             // this wave's share of the output statistics, added to its own partial (passes of one op accumulate)
           sacc = wave_sum(sacc); qacc = wave_sum(qacc);
           if (lane == 0) { stat[(g_stat_out * PNW + wave) * 2] += sacc; stat[(g_stat_out * PNW + wave) * 2 + 1] += qacc; }
         }
       }
+      PSTAMP_X(12);
       __syncthreads();                                    // red is reused; the output slab and the statistics are complete
       PSTAMP(3);
       pc = pn; off_c = off_n; st_c = st_n; ci = ni;
@@ -969,7 +989,7 @@ void pack_fragments(const float* prm, const GemmOp& g, PFragOp* fo, std::vector<
 }
 
 // One output pixel, a power-of-two width that fills the 512 threads with at most 8 K slices per column: the vector-ALU mat-vec (PIX_VEC).
-bool pix_vec_on() { static const bool on = !(std::getenv("SBM_PIX_VEC") && std::atoi(std::getenv("SBM_PIX_VEC")) == 0); return on; }
+bool pix_vec_on() { const char* e = std::getenv("SBM_PIX_VEC"); return !(e && std::atoi(e) == 0); }      // read at every model creation (the tests switch it)
 bool pix_vec_eligible(const GemmOp& g) {
   if (!pix_vec_on() || g.Hout * g.Wout != 1 || g.a.H * g.a.W > 16) return false;
   if (g.Npad != 64 && g.Npad != 128 && g.Npad != 256 && g.Npad != 512) return false;

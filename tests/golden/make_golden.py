@@ -263,11 +263,11 @@ class _Inert(types.ModuleType):
 class _Noise:
     """Deterministic stand-in for torch's normal draws; logs every draw in order."""
 
-    def __init__(self, seed):
-        self.seed, self.log = seed, []
+    def __init__(self, seed, scale=1.0):
+        self.seed, self.log, self.scale = seed, [], np.float32(scale)
 
     def _draw(self, kind, shape):
-        a = synth.noise(self.seed, len(self.log), tuple(shape))
+        a = synth.noise(self.seed, len(self.log), tuple(shape)) * self.scale
         self.log.append((kind, a))
         return torch.from_numpy(a)
 
@@ -537,8 +537,11 @@ def config45_cases():
     from unet_openai import UNetModel
     out = {}
     B, N, shape = 2, 50, (2, 3, 16, 16)
-    m4 = synth.fill_module_(Unet(dim=256, channels=3, dim_mults=(1, 2, 2, 2, 2), with_time_emb=True).eval())
-    um = synth.fill_module_(UNetModel(3, 128, 3, 2, (), 0.1, (1, 2, 4, 8), num_heads=1, use_z=True, z_dim=512).eval())
+    # tamed (synth.tame_output_: last layer x 0.01, every injected normal x 0.02) so that the REFERENCE trajectory stays O(1) .. O(10) at the
+    # recipe's beta = (0.1, 20) and rtol = 1e-4 / atol = 1e-4 max|x| is a real check of elements of ordinary size
+    m4 = synth.tame_output_(synth.fill_module_(Unet(dim=256, channels=3, dim_mults=(1, 2, 2, 2, 2), with_time_emb=True).eval()))
+    um = synth.tame_output_(synth.fill_module_(UNetModel(3, 128, 3, 2, (), 0.1, (1, 2, 4, 8), num_heads=1, use_z=True, z_dim=512).eval()))
+    out["tame"] = np.asarray([synth.OUTPUT_TAME, synth.NOISE_TAME], np.float32)
     zc = synth.noise(0xC5, 0, (B, 512))
     out["c5_zcond"] = zc
     zct = torch.from_numpy(zc)
@@ -551,7 +554,7 @@ def config45_cases():
             for pc in (False, True):
                 sde = S.VPSDE(0.1, 20.0, N)
                 seed = base + 2 * (order == "pc") + int(pc)
-                with _Noise(seed) as nz:
+                with _Noise(seed, synth.NOISE_TAME) as nz:
                     if order == "cp":
                         xm = S.uncond_sampler(shape, model, "cpu", sde, pc=pc, n_steps=1, target_snr=0.16)
                     else:

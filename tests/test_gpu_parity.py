@@ -362,6 +362,54 @@ def test_time_table_is_bit_identical_to_per_step_time_path(pkg):
     assert torch.equal(a, b)
 
 
+def test_update_kernels_that_advance_and_convert_leave_the_trajectory_bit_identical(pkg):
+    """Round 4: the step's last update kernel advances the step counter (its last workgroup) and stores the new state in the score net's
+    input layout as well, so a sampler step has no advance launch and no conversion launch.  Neither may change a bit: against the loop
+    with the conversion op in every forward (SBM_NO_FUSED_CVT), predictor only and predictor-corrector in both orders, graph and eager."""
+    import os
+    m = _unet(pkg, "tiny")
+    x0 = torch.randn(7, 2, 8, 8, device="cuda")
+    sde = pkg["sde"].VPSDE(0.1, 5.0, 40)
+    for kw in (dict(), dict(pc=True, order="cp"), dict(pc=True, order="pc"), dict(use_graph=False), dict(pc=True, order="pc", use_graph=False)):
+        outs = []
+        for env in ({}, {"SBM_NO_FUSED_CVT": "1"}):
+            os.environ.update(env)
+            try:
+                m.release_engines()
+                outs.append(pkg["sde"].uncond_sampler(tuple(x0.shape), m, "cuda", sde, x0=x0, seed=11, **kw).clone())
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        assert torch.equal(outs[0], outs[1]), kw
+    m.release_engines()
+
+
+def test_one_position_runs_match_the_mfma_path(pkg):
+    """Round 4: the 1x1 level of the pixel kernel runs as vector-ALU mat-vecs streamed through the AGPR ring (PIX_VEC runs) instead of
+    4-row MFMA passes (SBM_PIX_VEC=0): same results to float32 reassociation, forward and a 30-step sampler run, at B = 3 and at the bench's
+    B = 256; and the op-level programs (every op alone) still run -- the stamps tool builds them."""
+    import os
+    m = _unet(pkg, "P5")
+    sde = pkg["sde"].VPSDE(0.1, 5.0, 30)
+    for B in (3, 256):
+        x = torch.randn(B, 5, 8, 8, device="cuda"); t = torch.rand(B, device="cuda")
+        res = {}
+        for tag, env in (("vec", {}), ("mfma", {"SBM_PIX_VEC": "0"})):
+            os.environ.update(env)
+            try:
+                m.release_engines()
+                y = m(x, t).clone()
+                assert m._engine_for(B, 8, 8).info["uses_pix"]
+                res[tag] = (y, pkg["sde"].uncond_sampler((B, 5, 8, 8), m, "cuda", sde, x0=x, seed=5).clone())
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+        for i in (0, 1):
+            a, b = res["vec"][i], res["mfma"][i]
+            assert float((a - b).abs().max()) <= (2e-5 if i == 0 else 1e-4) * float(b.abs().max()), (B, i)
+    m.release_engines()
+
+
 def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
     """Config-2 score net, B=256 (8 sample tiles = 8 XCD clusters): XCD-resident chain (the LEGACY path, SBM_PIX=0) vs one launch per
     layer."""
@@ -433,7 +481,8 @@ def test_pixel_kernel_matches_per_layer_kernels_at_bench_size(pkg):
 
 
 def test_full_size_sampling_run_is_path_and_shard_independent(pkg):
-    """BASELINE config 2 at full size (B = 256, 1000 reverse-SDE steps at the recipe's beta = (0.1, 20), in-kernel Philox noise).  The
+    """BASELINE config 2 at full size (B = 256, 1000 reverse-SDE steps, in-kernel Philox noise) at beta = (0.1, 20) -- the CelebA recipe's range
+    (train_cel.sh:11), the stiffest the scripts use; PolyMNIST's own recipe is (1, 5) (train_poly.sh:17) and the bench runs SURVEY's (0.1, 5).  The
     samples do not depend on WHICH kernels carry the low-resolution levels (sample-owned pixel kernel down from 8x8 = the default, down
     from 4x4, or one launch per layer) beyond float32 reassociation -- measured 5e-7 of max|x| (tools/shard_check.py), bound 1e-5 -- nor
     on how the batch is split: on the default path every op from 8x8 down is sample-owned, so two shards of 128 keyed by their global
