@@ -69,8 +69,10 @@ struct PixItem {                          // one pass of a GEMM: up to 8 column 
   const float* bias; const float* gn_s; const float* gn_b1;     // never null: a zero vector stands in
   float* out_g; float2* stat_g;           // workspace copies of the output / its statistics, when something outside the launch reads them
   int out_sub, res_sub;                   // floats between the four 16-row sub-slabs of a 64-row output / residual tensor
+  int rg_stride, perm_tab;                // phase-grouped transposed convolutions: steps between the row groups' OWN step lists (0: shared list); row table
+                                          // (16-entry units) that maps a pass row to its output pixel, -1 none
 };
-static_assert(sizeof(PixItem) == 144, "PixItem layout");
+static_assert(sizeof(PixItem) == 152, "PixItem layout");
 
 struct PixOpD {
   int kind;                              // OP_GEMM, OP_DWCONV7, OP_GN_RES, OP_LINATTN, PIX_STAGE
@@ -336,7 +338,10 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
   // ---- loader state (per wave; survives the non-GEMM ops between two GEMMs) ----
   unsigned asel[PD];
   auto lane_off = [&](const PixItem* it) { return (unsigned)(((wave & ((1 << ldc(&it->gshift)) - 1)) * ldc(&it->grp_stride) + lane * 4) * 4); };   // bytes
-  auto slice_steps = [&](const PixItem* it) { return steps + ldc(&it->step_base) + (wave >> (ldc(&it->gshift) + ldc(&it->rshift))) * ldc(&it->nkp); };
+  auto slice_steps = [&](const PixItem* it) {
+    const int gs = ldc(&it->gshift), rs = ldc(&it->rshift);
+    return steps + ldc(&it->step_base) + (wave >> (gs + rs)) * ldc(&it->nkp) + ((wave >> gs) & ((1 << rs) - 1)) * ldc(&it->rg_stride);
+  };
   // output quads of a pass owned by this thread: (row, 4 columns) x 2
   struct Quads { int row[2], prow[2], col[2]; bool ok[2]; int total; };      // total: output quads of the pass (wave-uniform)
   auto quads_of = [&](const PixItem* it) {
@@ -601,8 +606,14 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         const PixOpD& o = ops[k + j];
         const int kd = ldc(&o.kind);
         if (dbg && b == 0 && tid == 0 && j > 0) dbg[k + j] = __builtin_amdgcn_s_memtime();
+#ifdef PIX_STAMP_VEC
+#define VSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && k + j < 96) dbg[128 + (k + j) * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VSTAMP(ph) do { } while (0)
+#endif
         const int out_lds = ldc(&o.out_lds), so = ldc(&o.stat_out);
         float ov = 0.f;                                     // this thread's stored output (0 when it owns none): the op's statistics
+        VSTAMP(0);
         if (kd == PIX_VEC) {
           const int sshift = ldc(&o.v_sshift), S = 1 << sshift, slice = tid & (S - 1), col = tid >> sshift;
           const int aoff = ((slice * 4) >> 4) * PCS + ((slice * 4) & 15);
@@ -624,6 +635,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
           // exhausted, with the next MFMA pass's first steps, which the ring held when the run began.  The activations are requested in front
           // of the wait.  Source-2 steps (bit 31: the fused 1x1 residual conv, which enters unnormalised) are scaled by 1 / rstd so that the
           // common GroupNorm scaling cancels, as on the MFMA path.
+          VSTAMP(1);
           i32x8p e_cur = ldc_x8(sc);
           auto slots4 = [&](auto sc_tag) __attribute__((always_inline)) {
             constexpr bool SC = decltype(sc_tag)::value;
@@ -649,6 +661,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
           const int ns = ldc(&o.v_n1);                      // slots of this op, a multiple of 4
           if (gn && ldc(&o.v_n2) > 0) for (int si = 0; si < ns; si += PD) slots4(std::true_type{});
           else for (int si = 0; si < ns; si += PD) slots4(std::false_type{});
+          VSTAMP(2);
           float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
           if (S >= 2) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
           if (S >= 4) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
@@ -691,6 +704,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
           }
         }
         if (j + 1 < run) PIX_REQUEST_SMALL(ops[k + j + 1]);
+        VSTAMP(3);
         if (so >= 0) {
           const float sacc = wave_sum(ov), qacc = wave_sum(ov * ov);
           if (lane == 0) { stat[(so * PNW + wave) * 2] = sacc; stat[(so * PNW + wave) * 2 + 1] = qacc; }
@@ -741,15 +755,21 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       PSTAMP_X(1);
       const int flags = ldc(&pc->flags);
       const bool small = (flags & PIF_SMALL) != 0, gn = (flags & PIF_GN) != 0, scale2 = (flags & PIF_SCALE2) != 0;
+      // The folded GroupNorm's mean / rstd are needed in the EPILOGUE only (the K loop runs on raw activations) -- except by the few ops with a
+      // fused residual conv, whose source 2 is scaled by 1 / rstd inside the loop.  Computed here by all 512 threads they cost every pass
+      // 0.3 us of dependent LDS reads and fp64 arithmetic in front of the K loop (round 4, -DPIX_STAMP_PRE); wave 0 -- the oldest wave, which
+      // wins the matrix pipe from its SIMD partner and reaches the barrier behind the K loop first -- computes them there instead, while it
+      // would wait, and hands them over through LDS.
       float mean = 0.f, rstd = 1.f, inv_r = 1.f;
-      if (gn) {
+      auto gn_moments = [&]() {
         float su, sq;
         stat_sum(ldc(&pc->gn_stat), &su, &sq);
         const float ginv = ldc(&pc->gn_inv);
         const double mean_d = (double)su * (double)ginv;
         double var = (double)sq * (double)ginv - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
         mean = (float)mean_d; rstd = rsqrtf((float)var + 1e-5f); inv_r = sqrtf((float)var + 1e-5f);
-      }
+      };
+      if (gn && scale2) gn_moments();
       PSTAMP_X(2);
       const int g_stat_out = ldc(&pc->stat_out);
       if ((flags & PIF_FIRST) && g_stat_out >= 0 && lane == 0) { stat[(g_stat_out * PNW + wave) * 2] = 0.f; stat[(g_stat_out * PNW + wave) * 2 + 1] = 0.f; }
@@ -832,8 +852,10 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
 #pragma unroll
         for (int v = 0; v < 4; ++v) red[wave * 512 + v * 64 + lane] = acc0[v] + acc1[v];
       }
+      if (gn && !scale2 && wave == 0) { gn_moments(); if (lane == 0) { scr[0] = mean; scr[1] = rstd; } }      // (scr: nothing else uses it during a GEMM pass)
       __syncthreads();
       PSTAMP(2);
+      if (gn && !scale2) { mean = scr[0]; rstd = scr[1]; }
       // epilogue: operands out of the AGPRs (everything but the 16 loads just issued for the next pass has landed)
       {
         f32x4p eb[2], es[2], eg[2];
@@ -849,12 +871,14 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         const int res_row[4] = {ldc(&pc->res_row[0]), ldc(&pc->res_row[1]), ldc(&pc->res_row[2]), ldc(&pc->res_row[3])};
         float* out_g = ldc(&pc->out_g); float2* stat_g = ldc(&pc->stat_g);
         float sacc = 0.f, qacc = 0.f;
+        const int perm_tab = ldc(&pc->perm_tab);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           // the epilogue is VALU-issue-bound (two waves per SIMD, four cycles per instruction): a wave none of whose lanes owns a quad j of
           // this pass -- every pass of fewer than 1024 / 512 output quads -- skips the whole block instead of executing it masked
           if (wave * 64 + j * PNT >= q.total) continue;
-          const int row = q.row[j], col = q.col[j];
+          const int row = perm_tab >= 0 ? (int)rtab[perm_tab * 16 + q.row[j]] : q.row[j];      // (phase-grouped passes: pass row -> output pixel)
+          const int col = q.col[j];
           const int cw = col - grp0 * gw, grp = small ? cw >> 6 : cw >> 5, sub = cw & (gw - 1);
           const int unit = ((q.prow[j] >> 4) << gshift) | grp;       // the wave (of K slice 0) that owns this output: [column group | row group]
           f32x4p t = {0.f, 0.f, 0.f, 0.f};
@@ -989,6 +1013,7 @@ void pack_fragments(const float* prm, const GemmOp& g, PFragOp* fo, std::vector<
 }
 
 // One output pixel, a power-of-two width that fills the 512 threads with at most 8 K slices per column: the vector-ALU mat-vec (PIX_VEC).
+bool pix_phase_on() { const char* e = std::getenv("SBM_PIX_PHASE"); return !(e && std::atoi(e) == 0); }   // phase-grouped transposed convolutions (read at model creation)
 bool pix_vec_on() { const char* e = std::getenv("SBM_PIX_VEC"); return !(e && std::atoi(e) == 0); }      // read at every model creation (the tests switch it)
 bool pix_vec_eligible(const GemmOp& g) {
   if (!pix_vec_on() || g.Hout * g.Wout != 1 || g.a.H * g.a.W > 16) return false;
@@ -1254,12 +1279,24 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         // row tables: one per live tap (+ source 2), 16 or 64 output rows
         const int w2 = g.has2 ? g.a2.W : (g.has_res ? g.r.W : 1);
         const int nrows = P_out > 16 ? 64 : 16;
+        // A stride-2 transposed convolution onto 8x8: an output pixel of phase (oy & 1, ox & 1) has 4 of the 16 taps, so with rows in raster order
+        // every tap multiplies 48 zero rows of 64 (ups.2.3: 21 us for 2.1 MFLOP of live work).  PHASE-GROUPED: the pass's four row groups are the
+        // four phases (16 pixels each), every row group walks its OWN step list of 4 taps, and the epilogue maps pass rows back to pixels.
+        const bool phased = pix_phase_on() && g.transposed && g.stride == 2 && P_out == 64 && (g.Wout & 1) == 0 && !g.has2 && !g.has_res && !g.gn && fo.groups * 4 == PNW;
+        int perm[64];
+        for (int r = 0; r < 64; ++r) perm[r] = r;
+        if (phased) {
+          const int hw = g.Wout / 2;
+          for (int r = 0; r < 64; ++r) { const int ph = r >> 4, i = r & 15; perm[r] = (2 * (i / hw) + (ph >> 1)) * g.Wout + 2 * (i % hw) + (ph & 1); }
+        }
         std::vector<int> tab_of;
         for (int tp : fo.taps) {
           int rows[64];
-          for (int r = 0; r < nrows; ++r) rows[r] = r < P_out ? tap_source_pixel(r / g.Wout, r % g.Wout, tp / g.KW, tp % g.KW, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W) : -1;
+          for (int r = 0; r < nrows; ++r) { const int px = perm[r]; rows[r] = px < P_out ? tap_source_pixel(px / g.Wout, px % g.Wout, tp / g.KW, tp % g.KW, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W) : -1; }
           tab_of.push_back(b.add_rowtab(rows, nrows, g.a.ld));
         }
+        proto.perm_tab = -1;
+        if (phased) { proto.perm_tab = (int)b.rowtab.size() / 16; for (int r = 0; r < 64; ++r) b.rowtab.push_back((unsigned short)perm[r]); }
         int tab2 = 0;
         {
           int rows[64];
@@ -1273,6 +1310,38 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         const int kchunk = fo.small ? 1 : 2;               // LDS chunks per K step
         const int nrg = P_out > 16 ? 4 : 1;
         item_first = b.items.size();
+        if (phased) {
+          // one pass: fo.groups column groups x 4 phases = 8 waves, no K split; phase ph walks the taps that reach one of its 16 pixels
+          std::vector<std::vector<int>> ptaps(4);
+          for (int ph = 0; ph < 4; ++ph)
+            for (size_t ti = 0; ti < fo.taps.size(); ++ti) {
+              bool live = false;
+              for (int i = 0; i < 16 && !live; ++i) { const int px = perm[ph * 16 + i]; live = tap_source_pixel(px / g.Wout, px % g.Wout, fo.taps[ti] / g.KW, fo.taps[ti] % g.KW, g.stride, g.pad, g.transposed, g.up, g.a.H, g.a.W) >= 0; }
+              if (live) ptaps[ph].push_back((int)ti);
+            }
+          size_t mx = 0; for (auto& v : ptaps) mx = std::max(mx, v.size());
+          const int nk = (int)mx * fo.ndc, nkp = (nk + PD - 1) / PD * PD;
+          PixItem it = proto;
+          it.step_base = (int)b.steps.size(); it.nkp = nkp; it.grp0 = 0; it.grp_stride = fo.F * 1024; it.rg0 = 0; it.rg_stride = nkp;
+          int sh = 0; while ((1 << sh) < fo.groups) ++sh; it.gshift = sh;
+          it.rshift = 2; it.kshift = 0;
+          for (int ph = 0; ph < 4; ++ph)
+            for (int j = 0; j < nkp; ++j) {
+              PixStep e;
+              if (j < (int)ptaps[ph].size() * fo.ndc) {
+                const int ti = ptaps[ph][j / fo.ndc], dc = j % fo.ndc;
+                const long long aoff = a_lds + (long long)dc * kchunk * PCS;
+                if (b.preset && aoff > 0xffff) return "pixel kernel: LDS offset out of the step table's range";
+                e.w_off = (unsigned)(fo.off + ((long long)ti * fo.ndc + dc) * 1024);
+                e.a_sel = (unsigned)(aoff & 0xffff) | ((unsigned)tab_of[ti] << 16);
+              } else {
+                e.w_off = (unsigned)fo.off;
+                e.a_sel = (unsigned)(a_lds & 0xffff);       // row table 0: every row reads zeros
+              }
+              b.steps.push_back(e);
+            }
+          b.items.push_back(it);
+        } else
         for (int g0 = 0; g0 < fo.groups;) {
           int grp = 1; while (grp * 2 <= PNW && grp * 2 <= fo.groups - g0) grp *= 2;
           int rgs = 1; while (rgs * 2 <= nrg && grp * rgs * 2 <= PNW) rgs *= 2;
@@ -1385,7 +1454,7 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
   if (act_floats > 0xffff) return "pixel kernel: the activations exceed the step table's LDS range";
   if (pix_lds_bytes(act_floats, (int)b.rowtab.size() / 16) > 160 * 1024) return "pixel kernel: the activations do not fit the LDS";
   if (b.items.empty()) {                                   // a run without a GEMM still needs one (never consumed) item for the loader's prologue
-    PixItem it{}; it.step_base = (int)b.steps.size(); it.nkp = PD; it.grp_stride = 0; it.P_out = 1; it.Npad = 32; it.bias = it.gn_s = it.gn_b1 = st.zero4;
+    PixItem it{}; it.step_base = (int)b.steps.size(); it.nkp = PD; it.grp_stride = 0; it.P_out = 1; it.Npad = 32; it.perm_tab = -1; it.bias = it.gn_s = it.gn_b1 = st.zero4;
     // (step_base is not 0: a one-position run may have put its slot table at the front of the step array)
     b.items.push_back(it);
     for (int j = 0; j < PNW * PD; ++j) b.steps.push_back(PixStep{0u, 0u});
