@@ -28,6 +28,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -85,7 +86,8 @@ struct PixOpD {
   const float* st_src; const float2* st_part; int st_ld, st_C, st_P, st_lds, st_stat, st_nparts;
   // PIX_VEC: out[n] = sum_k a[k] W[k][n] over 512 threads = N columns x S K-slices (N S = 512); steps of 8 KB: thread (column, slice) takes one float4 of weights
   // and the matching four activations of its slice.  Source 1 (v_n1 steps; GroupNorm folded as in the MFMA path) and source 2 (v_n2 steps, raw).
-  int v_run, v_stream, v_slots, v_pad2;   // on the FIRST op of a run: program ops in the run, step index where the run's slot table begins, its slots
+  int v_run, v_stream, v_slots, v_recs;   // on the FIRST op of a run: program ops in the run, step index where the run's slot table begins, its slots,
+                                          // step index of the run's 64-byte records (PixVecRec words, one record per program op of the run)
   int v_step_base, v_n1, v_n2, v_sshift;  // v_n1: slots (four steps each) of this op, a multiple of 4
   int v_Npad, v_nstore, v_act, v_ldo, v_gn, v_res_lds;     // v_res_lds: float offset of the residual ROW (-1 none)
   float v_gn_inv; int v_pad;
@@ -101,10 +103,29 @@ __device__ __forceinline__ PixStep ldc_step(const PixStep* p) {
   const i32x2p v = *(const __attribute__((address_space(4))) i32x2p*)(unsigned long long)p;
   return PixStep{(unsigned)v[0], (unsigned)v[1]};
 }
-typedef int i32x8p __attribute__((ext_vector_type(8)));
-// eight table words in ONE scalar load.  The step groups of the one-position runs are stored BLOCKED -- the eight weight offsets of a group, then
-// its eight activation selectors -- so that the loader and the consumer each need eight SGPRs, not sixteen (the kernel is short of them)
-__device__ __forceinline__ i32x8p ldc_x8(const void* p) { return *(const __attribute__((address_space(4))) i32x8p*)(unsigned long long)p; }
+// A 64-byte record as sixteen separate scalar words.  (NOT as one ext_vector_type(16) value: with the record in s[16:31] hipcc 7.2 read lane 4 --
+// the GroupNorm 1 / count -- out of the register that held lane 0, and in the loop-carried form kept the loop counter in the tuple's lane 4:
+// wrong moments, no diagnostic.  Separate loads from one base are merged into wide s_loads by the compiler itself, correctly.)
+struct Rec16 { int w[16]; __device__ __forceinline__ int operator[](int i) const { return w[i]; } };
+__device__ __forceinline__ Rec16 ldc_x16(const void* p) {
+  Rec16 r;
+  const __attribute__((address_space(4))) int* q = (const __attribute__((address_space(4))) int*)(unsigned long long)p;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) r.w[i] = q[i];
+  return r;
+}
+typedef Rec16 i32x16p;
+// eight table words (separate scalar words, for the same reason).  The step groups of the one-position runs are stored with the weight offsets
+// first and the four activation selectors behind them.
+struct Rec8 { int w[8]; __device__ __forceinline__ int operator[](int i) const { return w[i]; } };
+__device__ __forceinline__ Rec8 ldc_x8(const void* p) {
+  Rec8 r;
+  const __attribute__((address_space(4))) int* q = (const __attribute__((address_space(4))) int*)(unsigned long long)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.w[i] = q[i];
+  return r;
+}
+typedef Rec8 i32x8p;
 template <typename T> __device__ __forceinline__ T ldc(const T* p) {
   static_assert(sizeof(T) == 4 || sizeof(T) == 8, "ldc: 4- or 8-byte fields");
   if constexpr (sizeof(T) == 4) { const int v = *(const __attribute__((address_space(4))) int*)(unsigned long long)p; T r; __builtin_memcpy(&r, &v, 4); return r; }
@@ -387,9 +408,17 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     PIX_LOAD_SLOT(r, base_, off_c);
   }
   Quads q_cur = request_epilogue_operands(pc);
+  // {kind, passes} of every program op, packed eight ops to a scalar-cache line at the end of the step array (ops[0].pad): read from the 416-byte
+  // descriptors, the first word of every op was a miss of its own at the top of the op
+  const PixStep* opk = steps + ldc(&ops[0].pad);
   for (int k = 0; k < count; ++k) {
     const PixOpD& op = ops[k];
-    const int kind = ldc(&op.kind);
+#ifdef PIX_EXP_NOOPK
+    const PixStep kk = PixStep{(unsigned)ldc(&op.kind), (unsigned)ldc(&op.nitems)};
+#else
+    const PixStep kk = ldc_step(opk + k);
+#endif
+    const int kind = (int)kk.w_off;
     if (dbg && b == 0 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();
     if (kind == PIX_STAGE) {
       // (an opaque copy of the thread index: what is derived from it here stays here.  hipcc hoists every cheap tid expression of every branch
@@ -561,13 +590,17 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     }
     if (kind == PIX_VEC || kind == PIX_DW1 || kind == PIX_GNR1) {
       // A RUN of one-position ops (the 1x1 level and the strided convolution that enters it), v_run program ops long.  On the MFMA path such an
-      // op costs 4.4 us around a 1.3 us K loop -- partial tiles through LDS, two barriers, a 512-thread epilogue for 128 .. 256 outputs -- and a
-      // first version of this path that loaded an op's weights when the op began was no faster: a global load that nobody requested ahead costs
-      // 1 .. 3 us here (every workgroup asks the L2 for the same lines at the same moment).  So the run is ONE STREAM: the 8 KB weight steps of
-      // all its mat-vecs back to back (host-built, each op padded to a multiple of 16 steps), pulled through a register ring of two groups of 8
-      // steps that runs 16 steps ahead ACROSS op boundaries, and every op's small operands (bias / folded-GroupNorm tables, depth-wise centre
-      // taps, GroupNorm affine) are requested while the op before it finishes.  A mat-vec: thread = (column, K slice), 4 FMAs per 16-byte weight
-      // load, K slices are adjacent lanes and meet by DPP, the owner applies the epilogue and stores -- one barrier per op.
+      // op costs 4.4 us around a 1.3 us K loop -- partial tiles through LDS, two barriers, a 512-thread epilogue for 128 .. 256 outputs.  Two
+      // things make ops this small slow, and the run is built around both (round 4, tools/vec_stamps.py):
+      //  * a global load nobody requested ahead costs 1 .. 3 us (every workgroup asks the L2 for the same lines at the same moment).  So the
+      //    run's weights are ONE STREAM -- the 8 KB steps of all its mat-vecs back to back, each op padded to 16 steps -- pulled through the
+      //    AGPR ring 16 steps ahead ACROSS op boundaries, and every op's per-thread operands (bias / folded-GroupNorm tables, depth-wise centre
+      //    taps, GroupNorm affine) are requested while the op before it runs;
+      //  * an op's descriptor read when the op starts is a chain of scalar-cache misses (kind -> branch -> shapes -> pointers: ~1.5 us of
+      //    the 4 us such an op took).  So every op of a run has a 64-byte RECORD with all it needs (PixVecRec, host-built, contiguous), read
+      //    with one scalar load a whole op ahead.
+      // A mat-vec: thread = (column, K slice), 4 FMAs per 16-byte weight load, K slices are adjacent lanes and meet by DPP, the owner applies
+      // the epilogue and stores -- one barrier per op.
       const int run = ldc(&op.v_run);
       int tid = tid0; asm volatile("" : "+v"(tid));
       const int lane = tid & 63;
@@ -575,6 +608,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       // four activation selectors}
       int nload = ldc(&op.v_slots);                         // slots still to be requested
       const int* sc = reinterpret_cast<const int*>(steps + ldc(&op.v_stream));     // next slot to consume
+      const int* recs = reinterpret_cast<const int*>(steps + ldc(&op.v_recs));
       const unsigned vo0 = (unsigned)tid * 16u;
       if (nload > 0) {                                      // (a run without a mat-vec leaves the ring -- the next MFMA pass's first steps -- alone)
 #pragma unroll
@@ -582,55 +616,64 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         nload -= PD;
       }
       float pe0 = 0.f, pe1 = 0.f, pe2 = 0.f;
-      // the small per-thread operands of program op `o`, requested one op ahead.  (A macro, not a lambda: captured by a closure the three values
-      // lived on the stack -- scratch -- and every request was followed by a full wait.)  Pointers read from the tables are generic; cast to the
-      // global address space they give global_load, not flat_load.
-#define PIX_REQUEST_SMALL(o_) do { \
-        const PixOpD& o__ = (o_); \
-        const int kd__ = ldc(&o__.kind); \
-        if (kd__ == PIX_VEC) { \
-          const int npad__ = ldc(&o__.v_Npad), c0__ = tid >> ldc(&o__.v_sshift), c__ = c0__ < npad__ ? c0__ : npad__ - 1; \
-          pe0 = ldg(ldc(&o__.v_bias), c__); pe1 = ldg(ldc(&o__.v_gn_s), c__); pe2 = ldg(ldc(&o__.v_gn_b1), c__); \
-        } else if (kd__ == PIX_DW1) { \
-          const int C__ = ldc(&o__.dw.C), c__ = tid < C__ ? tid : C__ - 1; \
-          const float* dwc__ = ldc(&o__.dw.cond); \
-          const float* cond__ = dwc__ ? (cond_tab && ldc(&o__.dw.ctl) ? cond_tab + ldc(&o__.dw.cond_col) : dwc__ + (long long)b * ldc(&o__.dw.cond_ld)) : ldc(&o__.dw.bias); \
-          pe0 = ldg(ldc(&o__.dw.w), 24 * C__ + c__); pe1 = ldg(ldc(&o__.dw.bias), c__); pe2 = ldg(cond__, c__); \
+      // the per-thread operands of the op whose record is R_, requested one op ahead (pointers and shapes come out of the record: no chasing)
+#define PIX_RPTR(R_, i_) reinterpret_cast<const float*>(((unsigned long long)(unsigned)(R_)[i_]) | ((unsigned long long)(unsigned)(R_)[(i_) + 1] << 32))
+#define PIX_REQUEST_SMALL(R_) do { \
+        const int kd__ = (R_)[0] & 0xff; \
+        if (kd__ == (PIX_VEC & 0xff)) { \
+          const int c0__ = tid >> (((R_)[0] >> 8) & 0xf), c__ = c0__ < (R_)[9] ? c0__ : (R_)[9] - 1; \
+          pe0 = ldg(PIX_RPTR(R_, 10), c__); pe1 = ldg(PIX_RPTR(R_, 12), c__); pe2 = ldg(PIX_RPTR(R_, 14), c__); \
+        } else if (kd__ == (PIX_DW1 & 0xff)) { \
+          const int c__ = tid < (R_)[8] ? tid : (R_)[8] - 1; \
+          const float* dwc__ = PIX_RPTR(R_, 14); \
+          const float* cond__ = dwc__ ? (cond_tab && (((R_)[0] >> 19) & 1) ? cond_tab + (R_)[9] : dwc__ + (long long)b * (R_)[1]) : PIX_RPTR(R_, 12); \
+          pe0 = ldg(PIX_RPTR(R_, 10), c__); pe1 = ldg(PIX_RPTR(R_, 12), c__); pe2 = ldg(cond__, c__); \
           if (!dwc__) pe2 = 0.f; \
         } else { \
-          const int C__ = ldc(&o__.gr.C), c__ = tid < C__ ? tid : C__ - 1; \
-          pe0 = ldg(ldc(&o__.gr.gamma), c__); pe1 = ldg(ldc(&o__.gr.beta), c__); \
+          const int c__ = tid < (R_)[8] ? tid : (R_)[8] - 1; \
+          pe0 = ldg(PIX_RPTR(R_, 10), c__); pe1 = ldg(PIX_RPTR(R_, 12), c__); \
         } } while (0)
-      PIX_REQUEST_SMALL(op);
+      // (The records are NOT carried from one op to the next as 16-register vectors: hipcc 7.2 kept such a loop-carried tuple in s[16:31] and
+      // the loop counter in s20 -- lane 4, the GroupNorm 1 / count -- at the same time.  Each op reads its own record, and TOUCHES the next
+      // one's line a whole op ahead, so that read is a scalar-cache hit.)
+      { const i32x16p r0 = ldc_x16(recs); PIX_REQUEST_SMALL(r0); }
+      int touch = 0;
       for (int j = 0; j < run; ++j) {
-        const PixOpD& o = ops[k + j];
-        const int kd = ldc(&o.kind);
+        const i32x16p rc = ldc_x16(recs + 16 * j);
+        if (touch == 0x7f5a5a5a) asm volatile("s_nop 0");     // (consumes the previous op's touch: never true)
+        touch = ldc(recs + 16 * (j + 1 < run ? j + 1 : j));      // first touch of the NEXT op's record line, a whole op ahead
+        const int kd = rc[0] & 0xff;
         if (dbg && b == 0 && tid == 0 && j > 0) dbg[k + j] = __builtin_amdgcn_s_memtime();
 #ifdef PIX_STAMP_VEC
 #define VSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && k + j < 96) dbg[128 + (k + j) * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define VSTAMP(ph) do { } while (0)
 #endif
-        const int out_lds = ldc(&o.out_lds), so = ldc(&o.stat_out);
+        const int out_lds = rc[5], so = rc[3];
+        const bool slow = ((rc[0] >> 18) & 1) != 0;          // results / statistics also leave the launch: those pointers stay in the big descriptor
         float ov = 0.f;                                     // this thread's stored output (0 when it owns none): the op's statistics
+        // The op's per-thread operands (requested while the previous op ran) are taken HERE, before this op's slot loop issues ring loads the
+        // compiler cannot see: vector-memory loads complete in order, and a compiler-placed wait for these three values behind sixteen newer
+        // ring loads waited for the NEXT op's weights (1 us per op in the first version, tools/vec_stamps.py).
+        float qe0 = pe0, qe1 = pe1, qe2 = pe2;
+#ifndef PIX_EXP_NOPIN
+        asm volatile("" : "+v"(qe0), "+v"(qe1), "+v"(qe2));
+#endif
         VSTAMP(0);
-        if (kd == PIX_VEC) {
-          const int sshift = ldc(&o.v_sshift), S = 1 << sshift, slice = tid & (S - 1), col = tid >> sshift;
+        if (kd == (PIX_VEC & 0xff)) {
+          const int sshift = (rc[0] >> 8) & 0xf, S = 1 << sshift, slice = tid & (S - 1), col = tid >> sshift;
           const int aoff = ((slice * 4) >> 4) * PCS + ((slice * 4) & 15);
-          const bool gn = ldc(&o.v_gn) != 0;
+          const bool gn = ((rc[0] >> 16) & 1) != 0;
           float mean = 0.f, rstd = 1.f, inv_r = 1.f;
           if (gn) {
             float su, sq;
-            stat_sum(ldc(&o.gn_stat), &su, &sq);
-            const float ginv = ldc(&o.v_gn_inv);
+            stat_sum(rc[2], &su, &sq);
+            const float ginv = __builtin_bit_cast(float, rc[4]);
             const double mean_d = (double)su * (double)ginv;
             double var = (double)sq * (double)ginv - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
             mean = (float)mean_d; rstd = rsqrtf((float)var + 1e-5f); inv_r = sqrtf((float)var + 1e-5f);
           }
           f32x4p acc = {0.f, 0.f, 0.f, 0.f};
-          // a group of 8 steps out of one half of the ring, then that half's refill 16 steps further down the stream (the next op's first
-          // groups when this op has no more).  Source-2 steps (bit 31: the fused 1x1 residual conv, which enters unnormalised) are scaled by
-          // 1 / rstd so that the common GroupNorm scaling cancels, as on the MFMA path.
           // one slot: four steps out of the ring, then the slot's refill four slots further down the stream -- or, once the run's stream is
           // exhausted, with the next MFMA pass's first steps, which the ring held when the run began.  The activations are requested in front
           // of the wait.  Source-2 steps (bit 31: the fused 1x1 residual conv, which enters unnormalised) are scaled by 1 / rstd so that the
@@ -658,65 +701,80 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
               else { const PixStep pe_ = ldc_step(st_c + r); const float* base_ = frag + pe_.w_off; PIX_LOAD_SLOT(r, base_, off_c); }
             }
           };
-          const int ns = ldc(&o.v_n1);                      // slots of this op, a multiple of 4
-          if (gn && ldc(&o.v_n2) > 0) for (int si = 0; si < ns; si += PD) slots4(std::true_type{});
+          const int ns = rc[1];                             // slots of this op, a multiple of 4
+#if defined(PIX_EXP_RECDBG)
+          if (false) for (int si = 0; si < ns; si += PD) slots4(std::true_type{});
+#elif defined(PIX_EXP_RECDBG2)
+          inv_r = 1.0f;
+          if (gn && ((rc[0] >> 17) & 1)) for (int si = 0; si < ns; si += PD) slots4(std::true_type{});
+#else
+          if (gn && ((rc[0] >> 17) & 1)) for (int si = 0; si < ns; si += PD) slots4(std::true_type{});
+#endif
           else for (int si = 0; si < ns; si += PD) slots4(std::false_type{});
           VSTAMP(2);
           float t = (acc[0] + acc[1]) + (acc[2] + acc[3]);
           if (S >= 2) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
           if (S >= 4) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
           if (S >= 8) t += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0x141, 0xF, 0xF, true));   // row_half_mirror
-          const int nstore = ldc(&o.v_nstore), res_lds = ldc(&o.v_res_lds);
-          if (gn) t = t * rstd + (pe2 - (mean * rstd) * pe1);
-          t += pe0;
+          const int nstore = rc[8], res_lds = rc[6];
+#ifdef PIX_EXP_DUMP
+          if (dbg && b == 0 && tid == 0 && gn && dbg[439] == 0) {
+            dbg[439] = 1 + k + j;
+            float su_, sq_; stat_sum(rc[2], &su_, &sq_);
+            const float vals[8] = {su_, sq_, mean, rstd, inv_r, t, qe0, qe1};
+            for (int q = 0; q < 8; ++q) dbg[440 + q] = (unsigned long long)__builtin_bit_cast(unsigned, vals[q]);
+            dbg[448] = (unsigned long long)(unsigned)rc[2]; dbg[449] = (unsigned long long)(unsigned)rc[4]; dbg[450] = (unsigned long long)(unsigned)qe2;
+          }
+#endif
+          if (gn) t = t * rstd + (qe2 - (mean * rstd) * qe1);
+          t += qe0;
           const bool own = slice == 0 && col < nstore;
           const int colc = col < nstore ? col : 0;
           if (res_lds >= 0) t += lds[res_lds + (colc >> 4) * PCS + (colc & 15)];
-          const float ot = ldc(&o.v_act) == ACT_GELU ? 0.5f * t * (1.0f + sbm_erf(t * 0.70710678118654752440f)) : t;      // (eligibility: GELU or none)
+          const float ot = ((rc[0] >> 12) & 0xf) == ACT_GELU ? 0.5f * t * (1.0f + sbm_erf(t * 0.70710678118654752440f)) : t;      // (eligibility: GELU or none)
           if (own) {
             lds[out_lds + pix_at(col, 0)] = ot;
-            if (ldc(&o.out_g)) ldc(&o.out_g)[(long long)b * ldc(&o.v_ldo) + col] = ot;
             ov = ot;
           }
-        } else if (kd == PIX_DW1) {
+          if (slow && own) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.out_g)[(long long)b * ldc(&o.v_ldo) + col] = ot; }
+        } else if (kd == (PIX_DW1 & 0xff)) {
           // depth-wise 7x7 at one position = its centre tap (unet_model.py:115 at 1x1; SURVEY appendix A "degenerate sizes")
-          const int C = ldc(&o.dw.C);
-          if (tid < C) {
-            const float a = fmaf(lds[ldc(&o.in_lds) + pix_at(tid, 0)], pe0, 0.f);
-            ov = a + (pe1 + pe2);
+          if (tid < rc[8]) {
+            const float a = fmaf(lds[rc[6] + pix_at(tid, 0)], qe0, 0.f);
+            ov = a + (qe1 + qe2);
             lds[out_lds + pix_at(tid, 0)] = ov;
-            if (ldc(&o.out_g)) ldc(&o.dw.out)[(long long)b * ldc(&o.dw.ldo) + tid] = ov;
+            if (slow) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.dw.out)[(long long)b * ldc(&o.dw.ldo) + tid] = ov; }
           }
         } else {
           // GroupNorm(1, C)(u) + x at one position (LinearAttention tail + Residual, unet_model.py:173-175, 21-27)
           float su, sq;
-          stat_sum(ldc(&o.gn_stat), &su, &sq);
-          const float inv_count = ldc(&o.gr.inv_count);
+          stat_sum(rc[2], &su, &sq);
+          const float inv_count = __builtin_bit_cast(float, rc[4]);
           const double mean_d = (double)su * (double)inv_count;
           double var = (double)sq * (double)inv_count - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
           const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + 1e-5));
-          const int C = ldc(&o.gr.C);
-          if (tid < C) {
-            const float u = lds[ldc(&o.in_lds) + pix_at(tid, 0)], x = lds[ldc(&o.x_lds) + pix_at(tid, 0)];
-            const float y = ((u - mean) * rstd) * pe0 + pe1 + x;
+          if (tid < rc[8]) {
+            const float u = lds[rc[6] + pix_at(tid, 0)], x = lds[rc[7] + pix_at(tid, 0)];
+            const float y = ((u - mean) * rstd) * qe0 + qe1 + x;
             lds[out_lds + pix_at(tid, 0)] = y;
-            if (ldc(&o.out_g)) ldc(&o.gr.out)[(long long)b * ldc(&o.gr.ldo) + tid] = y;
+            if (slow) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.gr.out)[(long long)b * ldc(&o.gr.ldo) + tid] = y; }
           }
         }
-        if (j + 1 < run) PIX_REQUEST_SMALL(ops[k + j + 1]);
+        if (j + 1 < run) { const i32x16p rn = ldc_x16(recs + 16 * (j + 1)); PIX_REQUEST_SMALL(rn); }
         VSTAMP(3);
         if (so >= 0) {
           const float sacc = wave_sum(ov), qacc = wave_sum(ov * ov);
           if (lane == 0) { stat[(so * PNW + wave) * 2] = sacc; stat[(so * PNW + wave) * 2 + 1] = qacc; }
         }
         __syncthreads();
-        if (ldc(&o.stat_g)) {                               // the plan's partial layouts (debug sub-ranges only): one (sum, sumsq) per 32-column block of a
-          if (tid == 0) {                                   // GEMM's output, one per pixel for the depth-wise op
+        if (slow) {                                         // the plan's partial layouts (debug sub-ranges only): one (sum, sumsq) per 32-column block of a
+          const PixOpD& o = ops[k + j];                     // GEMM's output, one per pixel for the depth-wise op
+          if (ldc(&o.stat_g) && tid == 0) {
             float su, sq;
             stat_sum(so, &su, &sq);
-            float2* dst = kd == PIX_VEC ? ldc(&o.stat_g) : ldc(&o.dw.stat);
-            if (kd == PIX_VEC) {
-              const int nstore = ldc(&o.v_nstore), nblk = (nstore + 31) >> 5;
+            float2* dst = kd == (PIX_VEC & 0xff) ? ldc(&o.stat_g) : ldc(&o.dw.stat);
+            if (kd == (PIX_VEC & 0xff)) {
+              const int nstore = rc[8], nblk = (nstore + 31) >> 5;
               for (int bk = 0; bk < nblk; ++bk) {
                 float s32 = 0.f, q32 = 0.f;
                 for (int c = bk * 32; c < bk * 32 + 32 && c < nstore; ++c) { const float v = lds[out_lds + pix_at(c, 0)]; s32 += v; q32 += v * v; }
@@ -745,7 +803,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
 #define PSTAMP(ph) PSTAMP_AT(ph)
 #define PSTAMP_X(id) do { } while (0)
 #endif
-    const int g_nitems = ldc(&op.nitems);
+    const int g_nitems = (int)kk.a_sel;
     for (int it = 0; it < g_nitems; ++it) {
       PSTAMP_X(0);
       const int ni = ci + 1 < nitems ? ci + 1 : 0;
@@ -1067,6 +1125,34 @@ struct PBuilder {
     ops[run_first].v_slots = run_slots;
     // word 1 of a slot's entry: the weight offset of the slot FOUR further down the stream -- what the consumer of this slot requests next
     for (int sidx = 0; sidx + PD < run_slots; ++sidx) steps[run_stream + 4 * sidx].a_sel = steps[run_stream + 4 * (sidx + PD)].w_off;
+    // the run's records: 16 words per program op, everything the op's hot path needs (the kernel reads record j + 1 while op j runs)
+    ops[run_first].v_recs = (int)steps.size();
+    const int nrun = ops[run_first].v_run;
+    for (int j = 0; j < nrun; ++j) {
+      const PixOpD& d = ops[run_first + j];
+      unsigned w[16] = {0};
+      auto put_ptr = [&](int i, const void* ptr) { const unsigned long long v = (unsigned long long)ptr; w[i] = (unsigned)v; w[i + 1] = (unsigned)(v >> 32); };
+      auto fbits = [](float f) { unsigned u; std::memcpy(&u, &f, 4); return u; };
+      const unsigned slow = (d.out_g || d.stat_g) ? 1u : 0u;
+      w[2] = (unsigned)d.gn_stat; w[3] = (unsigned)d.stat_out; w[5] = (unsigned)d.out_lds;
+      if (d.kind == PIX_VEC) {
+        w[0] = (unsigned)(PIX_VEC & 0xff) | ((unsigned)d.v_sshift << 8) | ((unsigned)d.v_act << 12) | ((unsigned)(d.v_gn ? 1 : 0) << 16) | ((unsigned)(d.v_n2 > 0 ? 1 : 0) << 17) | (slow << 18);
+        w[1] = (unsigned)d.v_n1; w[4] = fbits(d.v_gn_inv); w[6] = (unsigned)d.v_res_lds; w[8] = (unsigned)d.v_nstore; w[9] = (unsigned)d.v_Npad;
+        put_ptr(10, d.v_bias); put_ptr(12, d.v_gn_s); put_ptr(14, d.v_gn_b1);
+      } else if (d.kind == PIX_DW1) {
+        w[0] = (unsigned)(PIX_DW1 & 0xff) | (slow << 18) | ((unsigned)(d.dw.ctl ? 1 : 0) << 19);
+        w[1] = (unsigned)d.dw.cond_ld; w[6] = (unsigned)d.in_lds; w[8] = (unsigned)d.dw.C; w[9] = (unsigned)d.dw.cond_col;
+        put_ptr(10, d.dw.w + 24 * (long long)d.dw.C); put_ptr(12, d.dw.bias); put_ptr(14, d.dw.cond);
+      } else {
+        w[0] = (unsigned)(PIX_GNR1 & 0xff) | (slow << 18);
+        w[4] = fbits(d.gr.inv_count); w[6] = (unsigned)d.in_lds; w[7] = (unsigned)d.x_lds; w[8] = (unsigned)d.gr.C;
+        put_ptr(10, d.gr.gamma); put_ptr(12, d.gr.beta);
+      }
+      if (preset && std::getenv("SBM_PIX_DUMP_RECS"))
+        fprintf(stderr, "rec run@%d op %d kind %d: w0 %08x slots/ld %d gn_stat %d stat_out %d ginv %08x out_lds %d w6 %d w7 %d w8 %d w9 %d | v_n1 %d v_n2 %d step_base %d\n", run_first, j, d.kind, w[0], (int)w[1],
+                (int)w[2], (int)w[3], w[4], (int)w[5], (int)w[6], (int)w[7], (int)w[8], (int)w[9], d.v_n1, d.v_n2, d.v_step_base);
+      for (int q = 0; q < 8; ++q) steps.push_back(PixStep{w[2 * q], w[2 * q + 1]});
+    }
     run_first = -1; run_stream = -1; run_slots = 0;
   }
   void push_op(const PixOpD& d) {
@@ -1459,6 +1545,8 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
     b.items.push_back(it);
     for (int j = 0; j < PNW * PD; ++j) b.steps.push_back(PixStep{0u, 0u});
   }
+  b.ops[0].pad = (int)b.steps.size();                      // the kernel's {kind, passes} table, one entry per program op
+  for (const PixOpD& d : b.ops) b.steps.push_back(PixStep{(unsigned)d.kind, (unsigned)(d.kind == OP_GEMM ? d.nitems : 0)});
   PProgram p;
   p.n_ops = (int)b.ops.size(); p.n_items = (int)b.items.size(); p.n_rowtab = (int)b.rowtab.size() / 16; p.act_floats = act_floats;
   for (const PixOpD& d : b.ops) p.kinds.push_back(d.kind * 1000 + (d.kind == OP_GEMM ? d.nitems : 0));
