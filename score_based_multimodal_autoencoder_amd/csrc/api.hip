@@ -419,7 +419,7 @@ int sbm_debug_forward_range(sbm_model* m, const float* in_dev, const float* t_de
     const char* e;
     if (m->plan.ops[i].chain) {                      // like run_plan: consecutive chain ops of the range share one launch
       while (i + n < last && i + n < nops && m->plan.ops[i + n].chain) ++n;
-      e = launch_chain(m->dp, i, n, st);
+      e = launch_chain(m->dp, i, n, st, out_dev);
     } else if (m->plan.ops[i].row) {
       while (i + n < last && i + n < nops && m->plan.ops[i + n].row) ++n;
       e = launch_rowrun(m->dp, i, n, st);
@@ -501,7 +501,7 @@ int sbm_debug_chain_stamps(sbm_model* m, int first, int count, unsigned long lon
   HIPCHK(hipMalloc(&d, sizeof(unsigned long long) * 1024));
   HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 1024));
   g_chain_dbg = d;
-  const char* e = launch_chain(m->dp, first, count, m->own);
+  const char* e = launch_chain(m->dp, first, count, m->own, m->d_score);
   g_chain_dbg = nullptr;
   if (e) { (void)hipFree(d); return fail(e); }
   HIPCHK(hipStreamSynchronize(m->own));
@@ -542,7 +542,7 @@ int sbm_debug_pix_stamps(sbm_model* m, int first, int count, unsigned long long*
   HIPCHK(hipMemset(d, 0, sizeof(unsigned long long) * 512));
   for (int rep = 0; rep < 3; ++rep) {
     g_pix_dbg = d;
-    const char* e = launch_pixrun(m->dp, first, count, m->own);
+    const char* e = launch_pixrun(m->dp, first, count, m->own, m->d_score);
     g_pix_dbg = nullptr;
     if (e) { (void)hipFree(d); return fail(e); }
     HIPCHK(hipStreamSynchronize(m->own));
@@ -614,7 +614,7 @@ int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev,
       } else if (m->plan.ops[i].chain) {
         while (i + n < nops && m->plan.ops[i + n].chain && !(skip_time && m->plan.ops[i + n].time_path)) ++n;
         if (n > CHAIN_MAX_OPS) n = CHAIN_MAX_OPS;              // one launch per event pair
-        e = launch_chain(m->dp, i, n, st);
+        e = launch_chain(m->dp, i, n, st, out_dev);
         bucket.push_back(m->dp.use_pix ? 14 : 11);
       } else if (m->plan.ops[i].row) {
         while (i + n < nops && m->plan.ops[i + n].row) ++n;

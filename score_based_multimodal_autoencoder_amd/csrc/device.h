@@ -177,12 +177,12 @@ struct DevPlan {
   PixState* pix = nullptr;              // ... and their state (owned by the model handle; released by pixrun_release)
 };
 // pixrun.hip: the 4x4 / 2x2 / 1x1 levels, one sample per workgroup, activations in LDS
-const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st);
+const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out = nullptr);   // ext_out: the plan's external NCHW output, for a run that ends in it
 const char* pixrun_prepare(DevPlan& dp, const float* host_params, double* frag_mb);   // host_params: the plan's packed weights (host copy)
 void pixrun_release(DevPlan& dp);
 extern unsigned long long* g_pix_dbg;
 int pixrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap);   // diagnostics: kind * 1000 + taps per program op
-const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st);
+const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out = nullptr);
 const char* chain_launch_geometry(int cus, int* grid, int* block);   // verifies that the whole grid can be resident
 int chain_variant_groups();
 bool qkv_linattn_fusable(const Plan& plan, int i);            // ops i (to_qkv GEMM) and i + 1 (LinearAttention core)

@@ -1717,7 +1717,7 @@ void prepare_layer_kernels() {
 
 const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ext_out, hipStream_t st) {
   const Plan& plan = *dp.plan; const Op& op = plan.ops[idx]; const float* prm = dp.prm; float* ws = dp.ws;
-  if (op.chain) return launch_chain(dp, idx, 1, st);
+  if (op.chain) return launch_chain(dp, idx, 1, st, ext_out);
   if (op.row) return launch_rowrun(dp, idx, 1, st);
   switch (op.kind) {
     case OP_GEMM: return launch_gemm(op.g, dp.hot[idx], ext_in, ext_out, st);
@@ -1869,7 +1869,7 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
     }
     if (plan.ops[i].chain) {                        // a maximal run of chain ops is ONE launch
       while (i + n < (int)plan.ops.size() && plan.ops[i + n].chain && !skipped(i + n)) ++n;
-      e = launch_chain(dp, i, n, st);
+      e = launch_chain(dp, i, n, st, ext_out);
     } else if (plan.ops[i].row) {                   // ... and so is a run of row-kernel ops (the one-position level)
       while (i + n < (int)plan.ops.size() && plan.ops[i + n].row && !skipped(i + n)) ++n;
       e = launch_rowrun(dp, i, n, st);

@@ -55,7 +55,7 @@ constexpr int P_RED_F = PNW * 512, P_STAT_SLOTS = 64, P_SCR_F = 4352;
 
 struct PixStep { unsigned w_off; unsigned a_sel; };   // w_off: float offset (fragment arena) of the step's block for column group 0 of the pass;
                                                       // a_sel = LDS float offset of the step's first chunk | row table << 16 | source 2 << 31
-enum : int { PIF_SMALL = 1, PIF_GN = 2, PIF_SCALE2 = 4, PIF_FIRST = 8, PIF_LAST = 16 };
+enum : int { PIF_SMALL = 1, PIF_GN = 2, PIF_SCALE2 = 4, PIF_FIRST = 8, PIF_LAST = 16, PIF_NCHW = 32 };      // PIF_NCHW: the output is the plan's external (B, N, H, W) tensor
 struct PixItem {                          // one pass of a GEMM: up to 8 column groups (32 columns, or 64 on the 4-row path) -- and EVERYTHING the pass needs,
                                           // so that the kernel reads nothing but this table (scalar loads) on the GEMM path
   int step_base, nkp;                     // step lists of the K slices: step_base + slice * nkp, nkp a multiple of PD
@@ -335,7 +335,7 @@ __device__ __forceinline__ void pix_linattn(float* lds, float* scr, int tid, int
 
 __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict__ ops, int count, const PixItem* __restrict__ items, int nitems, const PixStep* __restrict__ steps,
                                                         const unsigned short* __restrict__ rowtab, int nrowtab, const float* __restrict__ frag, const StepCtl* __restrict__ ctl, int B,
-                                                        int act_floats, unsigned long long* dbg) {
+                                                        int act_floats, unsigned long long* dbg, float* __restrict__ ext_out) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* red = lds + act_floats;                         // [8 waves][512]: 16 rows x 32 columns, or 4 rows x 64 columns
   float* stat = red + P_RED_F;                           // [slots][8 waves][2]: per-wave partial (sum, sumsq); readers add the eight in wave order
@@ -955,6 +955,10 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             }
             if (out_lds >= 0) *reinterpret_cast<f32x4p*>(lds + out_lds + pix_at2(col, row, out_sub)) = o;
             if (out_g) *reinterpret_cast<f32x4p*>(out_g + ((long long)row * B + b) * ldo + col) = o;
+            if (flags & PIF_NCHW) {                       // the plan's external output, (B, nstore, P_out): the last conv of a score net
+#pragma unroll
+              for (int i = 0; i < 4; ++i) if (col + i < nstore) ext_out[((long long)b * nstore + col + i) * P_out + row] = o[i];
+            }
             sacc += o[0] + o[1] + o[2] + o[3]; qacc += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
           }
           if (stat_g) {                                    // the plan's partial layout: one (sum, sumsq) per (pixel, 32-column block) = 8 consecutive threads
@@ -1002,7 +1006,7 @@ struct PFragOp {                          // fragment-order copy of one GEMM op'
 };
 
 struct PProgram { PixOpD* d_ops = nullptr; PixItem* d_items = nullptr; PixStep* d_steps = nullptr; unsigned short* d_rowtab = nullptr;
-                  int n_ops = 0, n_items = 0, n_rowtab = 0, act_floats = 0; std::vector<int> kinds; };
+                  int n_ops = 0, n_items = 0, n_rowtab = 0, act_floats = 0; bool needs_ext_out = false; std::vector<int> kinds; };
 
 }  // namespace
 
@@ -1026,9 +1030,9 @@ bool pix_tap_live(const GemmOp& g, int ky, int kx) {
 
 const char* pix_gemm_supported(const GemmOp& g) {
   const int P_out = g.Hout * g.Wout, P_in = g.a.H * g.a.W;
-  if ((P_out > 16 && P_out != 64) || (P_in > 16 && P_in != 64) || g.a_ext || g.out_nchw || g.w_pix_stride || g.bias_pix_stride || g.a_bcast || g.a_rows) return "pixel kernel: unsupported GEMM op";
+  if ((P_out > 16 && P_out != 64) || (P_in > 16 && P_in != 64) || g.a_ext || (g.out_nchw && (g.crop_y || g.crop_x || g.Hn != g.Hout || g.Wn != g.Wout || g.stat_off >= 0)) || g.w_pix_stride || g.bias_pix_stride || g.a_bcast || g.a_rows) return "pixel kernel: unsupported GEMM op";
   if (P_out == 64 && (g.up2 != 1 || (g.has_res && g.r.H * g.r.W != 64) || (g.has2 && g.a2.H * g.a2.W != 64))) return "pixel kernel: a 64-pixel output takes its residual / source 2 at its own resolution only";
-  if ((g.Kp & 31) || (g.has2 && (g.Kp2 & 31)) || (g.Npad & 31) || (g.out.C & 3)) return "pixel kernel: K and N must be multiples of 32";
+  if ((g.Kp & 31) || (g.has2 && (g.Kp2 & 31)) || (g.Npad & 31) || (!g.out_nchw && (g.out.C & 3))) return "pixel kernel: K and N must be multiples of 32";
   if (g.act != ACT_NONE && g.act != ACT_GELU) return "pixel kernel: activations other than GELU are not built in (no Unet op has one)";
   if (g.has2 && g.a2.H * g.a2.W > 16 && g.a2.H * g.a2.W != 64) return "pixel kernel: source 2 has an unsupported pixel count";
   return nullptr;
@@ -1074,7 +1078,7 @@ void pack_fragments(const float* prm, const GemmOp& g, PFragOp* fo, std::vector<
 bool pix_phase_on() { const char* e = std::getenv("SBM_PIX_PHASE"); return !(e && std::atoi(e) == 0); }   // phase-grouped transposed convolutions (read at model creation)
 bool pix_vec_on() { const char* e = std::getenv("SBM_PIX_VEC"); return !(e && std::atoi(e) == 0); }      // read at every model creation (the tests switch it)
 bool pix_vec_eligible(const GemmOp& g) {
-  if (!pix_vec_on() || g.Hout * g.Wout != 1 || g.a.H * g.a.W > 16) return false;
+  if (!pix_vec_on() || g.Hout * g.Wout != 1 || g.a.H * g.a.W > 16 || g.out_nchw) return false;
   if (g.Npad != 64 && g.Npad != 128 && g.Npad != 256 && g.Npad != 512) return false;
   if (g.act != ACT_NONE && g.act != ACT_GELU) return false;
   if (g.has2 && g.a2.H * g.a2.W != 1) return false;
@@ -1116,6 +1120,7 @@ struct PBuilder {
   const std::vector<PSlot>* preset = nullptr;
   std::vector<int> touched;
   const char* err = nullptr;
+  bool needs_ext_out = false;
   int run_first = -1, run_stream = -1, run_slots = 0;   // one-position run being assembled: its first program op, the step index of its slot table, its slots
 
   static bool run_kind(int kind) { return kind == PIX_VEC || kind == PIX_DW1 || kind == PIX_GNR1; }
@@ -1358,8 +1363,12 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         if (g.gn) { proto.gn_stat = b.stat_slot(g.gn_part_off); proto.gn_inv = g.gn_inv_count; proto.gn_s = dp.prm + g.gn_s_off; proto.gn_b1 = dp.prm + g.gn_b1_off; proto.rowstride = g.Npad; proto.flags |= PIF_GN; }
         if (g.gn && g.has2) proto.flags |= PIF_SCALE2;
         if (fo.small) proto.flags |= PIF_SMALL;
+        if (g.out_nchw) {                                   // no slab, no workspace copy: the pass stores into the external tensor (kernel argument)
+          proto.flags |= PIF_NCHW; proto.nstore = g.N; proto.out_g = nullptr; proto.out_lds = -1; proto.ldo = 0; b.needs_ext_out = true;
+        } else {
         proto.out_g = dp.ws + g.out.off;
         proto.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out, i);
+        }
         d.out_g = proto.out_g;
         if (g.stat_off >= 0) { proto.stat_out = b.stat_slot(g.stat_off); proto.stat_g = reinterpret_cast<float2*>(dp.ws + g.stat_off); d.stat_g = proto.stat_g; }
         // row tables: one per live tap (+ source 2), 16 or 64 output rows
@@ -1548,7 +1557,7 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
   b.ops[0].pad = (int)b.steps.size();                      // the kernel's {kind, passes} table, one entry per program op
   for (const PixOpD& d : b.ops) b.steps.push_back(PixStep{(unsigned)d.kind, (unsigned)(d.kind == OP_GEMM ? d.nitems : 0)});
   PProgram p;
-  p.n_ops = (int)b.ops.size(); p.n_items = (int)b.items.size(); p.n_rowtab = (int)b.rowtab.size() / 16; p.act_floats = act_floats;
+  p.n_ops = (int)b.ops.size(); p.n_items = (int)b.items.size(); p.n_rowtab = (int)b.rowtab.size() / 16; p.act_floats = act_floats; p.needs_ext_out = b.needs_ext_out;
   for (const PixOpD& d : b.ops) p.kinds.push_back(d.kind * 1000 + (d.kind == OP_GEMM ? d.nitems : 0));
   auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
     if (hipMalloc(dst, bytes ? bytes : 16) != hipSuccess) return false;
@@ -1640,17 +1649,18 @@ static const PProgram* pix_program(const DevPlan& dp, int first, int count, cons
   return &it->second;
 }
 
-const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st) {
+const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out) {
   if (!dp.pix) return "pixel kernel: the model has no pixel state";
   const Plan& plan = *dp.plan;
   const char* err = nullptr;
   const PProgram* p = pix_program(dp, first, count, &err);
   if (!p) return err;
+  if (p->needs_ext_out && !ext_out) return "pixel kernel: the run ends in the plan's external output, which this call does not have";
   const dim3 grid(plan.B), block(PNT);
   const size_t ldsb = pix_lds_bytes(p->act_floats, p->n_rowtab);
   if (g_prof_start) hipExtLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, g_prof_start, g_prof_stop, 0, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab,
-                                          dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg);
-  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab, dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg);
+                                          dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg, ext_out);
+  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab, dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg, ext_out);
   return nullptr;
 }
 

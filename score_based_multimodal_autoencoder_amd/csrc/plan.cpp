@@ -187,6 +187,9 @@ std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& c) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// pixel mode: the first and the last conv of a score net inside the sample-owned kernel (read when a plan is built)
+bool pix_io_on() { const char* e = std::getenv("SBM_PIX_IO"); return !(e && std::atoi(e) == 0); }
+
 // reference channel index -> channel index inside a (possibly concatenated, padded) buffer view
 struct ChanMap {
   std::vector<int> idx;
@@ -476,7 +479,9 @@ class Builder {
     choose_tile(B, P, nstore, &g.BM, &g.BN, s.kh * s.kw * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0), min_taps * (g.Kp / 32) + (s.has2 ? g.Kp2 / 32 : 0));
     // pixel mode: the sample-owned kernel keeps 16 rows per LDS slab, so a convolution that READS a larger grid (the strided one from
     // 8x8 down to 4x4) stays a per-layer launch
-    if (chain_pix > 0 && P <= chain_pix && !s.out_nchw && !(pix_mode && P_in_px > chain_pix)) { op.chain = 1; g.BM = 32; g.BN = 32; }
+    // (pixel mode also takes the conv that writes the plan's NCHW output, uncropped: the run then ends in the external tensor, SBM_PIX_IO=0 keeps it a launch of its own)
+    const bool nchw_pix = s.out_nchw && pix_mode && pix_io_on() && s.crop_y == 0 && s.crop_x == 0 && s.Hn == s.Hout && s.Wn == s.Wout && !s.want_stats;
+    if (chain_pix > 0 && P <= chain_pix && (!s.out_nchw || nchw_pix) && !(pix_mode && P_in_px > chain_pix)) { op.chain = 1; g.BM = 32; g.BN = 32; }
     if (row_op) { op.row = 1; op.chain = 0; g.BM = 32; g.BN = 32; }
     ConvResult res;
     if (s.out_nchw) {
