@@ -237,6 +237,12 @@ static int model_create_impl(int kind, const int* cfg, int batch, int in_pitch, 
   else m->plan.error = "unknown model kind";
   plan_set_pix_mode(0);
   if (!ok) { std::string e = m->plan.error; delete m; return fail("sbm_model_create: " + e); }
+  for (int i = 0; i + 1 < (int)m->plan.ops.size(); ++i) if (qkv_linattn_fusable(m->plan, i)) m->plan.ops[i].fuse_next = 1;
+  for (int i = 0; i + 3 < (int)m->plan.ops.size(); ++i)
+    if (attn_block_fusable(m->plan, i)) {
+      m->plan.ops[i].fuse_next = 2; m->plan.ops[i + 2].fuse_next = m->plan.ops[i + 3].fuse_next = -1;
+      pack_attn_block_fragments(&m->plan, i);          // appends the block's weights in the kernel's per-lane order to the parameter arena (before its upload)
+    }
   const size_t pbytes = m->plan.params.size() * sizeof(float), wbytes = (size_t)m->plan.ws_floats * sizeof(float);
   hipError_t e;
   if ((e = hipMalloc(&m->d_params, pbytes ? pbytes : 16)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(params)", e); }
@@ -245,7 +251,6 @@ static int model_create_impl(int kind, const int* cfg, int batch, int in_pitch, 
   if ((e = hipMemset(m->d_ws, 0, wbytes)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMemset(workspace)", e); }
   std::vector<float> host_params;
   host_params.swap(m->plan.params);                   // the plan no longer needs its host copy; the pixel kernel's packer (below) still does
-  for (int i = 0; i + 1 < (int)m->plan.ops.size(); ++i) if (qkv_linattn_fusable(m->plan, i)) m->plan.ops[i].fuse_next = 1;
   if (kind == SBM_UNET || kind == SBM_UNET_OA || kind == SBM_MLP) {
     if ((e = hipMalloc(&m->d_counter, 64)) != hipSuccess) { sbm_model_destroy(m); return fail_hip("hipMalloc(counter)", e); }
     (void)hipMemset(m->d_counter, 0, 64);
@@ -607,7 +612,11 @@ int sbm_model_profile_mix(sbm_model* m, const float* in_dev, const float* t_dev,
       if (skip_time && m->plan.ops[i].time_path) { ++i; continue; }
       const size_t l = bucket.size();
       arm_profile_events(ev[2 * l], ev[2 * l + 1]);            // events ride on the kernel's own dispatch: begin -> end of the kernel
-      if (m->plan.ops[i].fuse_next) {
+      if (m->plan.ops[i].fuse_next == 2) {
+        e = launch_attn_block(m->dp, i, st);
+        bucket.push_back(OP_LINATTN);
+        n = 4;
+      } else if (m->plan.ops[i].fuse_next == 1) {
         e = launch_qkv_linattn(m->dp, i, st);
         bucket.push_back(OP_LINATTN);
         n = 2;

@@ -187,6 +187,9 @@ const char* chain_launch_geometry(int cus, int* grid, int* block);   // verifies
 int chain_variant_groups();
 bool qkv_linattn_fusable(const Plan& plan, int i);            // ops i (to_qkv GEMM) and i + 1 (LinearAttention core)
 const char* launch_qkv_linattn(const DevPlan& dp, int i, hipStream_t st);
+bool attn_block_fusable(const Plan& plan, int i);             // ops i .. i + 3: the whole block as one attnblock_kernel launch
+const char* launch_attn_block(const DevPlan& dp, int i, hipStream_t st);
+void pack_attn_block_fragments(Plan* plan, int i);            // host: fragment-order copies of to_qkv's and to_out.0's weights (GemmOp::wt_off of ops i, i + 2)
 const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, float* ws, const GemmCold* cold_dev, GemmHot* hot, GemmCold* cold);
 
 // Enqueue every op of the plan on `st`.  Returns nullptr or a static error string.  No allocation, no

@@ -20,6 +20,8 @@
 #include <hip/hip_ext.h>
 
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 // Profiling hook: when an event pair is armed (sbm_model_profile), the next launch carries it on its own dispatch packet, so
 // hipEventElapsedTime(start, stop) is the kernel's begin->end time (what rocprofv3 --kernel-trace reports), free of the
@@ -1153,6 +1155,234 @@ __global__ __launch_bounds__(256) void linattn_qkv_kernel(const QkvAttnArgs qa) 
   }
 }
 
+// The whole 8x8 attention block of a ConvNeXt score net for ONE sample per workgroup (unet_model.py:21-27, 150-175: Residual(PreNorm(LinearAttention))),
+// 1024 threads = 4 heads x 4 waves: folded-GroupNorm to_qkv, the LinearAttention core of the four heads side by side, to_out.0, GroupNorm(1, C),
+// the residual.  Round 4: as (sample, head) workgroups (linattn_qkv_kernel) the block cost a 27 us launch -- 1024 workgroups of 42 KB LDS are 1.33
+// rounds of the chip -- plus 13 us of staging, a 1x1 GEMM pass and a GroupNorm op at the head of the pixel kernel's second launch.  Here every
+// sample is one workgroup (one round), the input tile and its statistics are read once instead of four times, and the attention output never
+// leaves LDS.  All MFMA: 32x32x2 for to_qkv (as before), 16x16x4 for the context, the output and to_out.0 (no partial tiles to merge).
+struct AttnBlockArgs {
+  QkvAttnArgs q;                          // to_qkv + core, as linattn_qkv_kernel takes them (q.a.out unused)
+  const float* Wo; const float* bo;       // to_out.0: [64][128] (k contiguous), [64]
+  const float* gamma; const float* beta;  // to_out.1: GroupNorm(1, 64) affine
+  float* out; int ldo; float inv_count;   // block output [pixel][B][ldo]; 1 / (64 channels x 64 pixels)
+  unsigned long long* dbg;                // SBM_ATTNBLOCK_STAMPS=1: s_memtime of workgroup 0 at the phase boundaries
+};
+#define AB_STAMP(i) do { if (ab.dbg && blockIdx.x == 0 && threadIdx.x == 0) ab.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+constexpr int AB_QLD = 33, AB_HT = 68;
+constexpr int AB_HEAD_F = 64 * AB_QLD + 64 * 32 + 64 * 32 + 32 * 32 + 8 * 32;      // sq | sk | sv | ctx | kred
+constexpr int AB_LDS_F = 64 * AB_HT + 4 * AB_HEAD_F + 64;
+constexpr int AB_LDS_BYTES = AB_LDS_F * 4 + 2 * 16 * 8 + 16;
+
+__global__ __launch_bounds__(1024) void attnblock_kernel(const AttnBlockArgs ab) {
+  const QkvAttnArgs& qa = ab.q; const AttnArgs& a = qa.a;
+  extern __shared__ __attribute__((aligned(16))) float ab_lds[];
+  AB_STAMP(0);
+  float* ht = ab_lds;                                             // block input tile [pixel][64 + 4] (= the residual)
+  float* hb = ht + 64 * AB_HT;
+  float* wstat = hb + 4 * AB_HEAD_F;                              // [16 waves][2] (sum, sumsq) of to_out.0's output, then {mean, rstd} at [32], [33]
+  double* sred = reinterpret_cast<double*>(wstat + 64);           // [2][16]
+  // wave -> (head h = wave & 3, quarter wq = wave >> 2): waves w, w + 4, w + 8, w + 12 share a SIMD, so every SIMD holds one head's four quarters --
+  // 2 + 2 + 1 + 1 of the 24 to_qkv tiles (with the quarters of one head on four SIMDs, two SIMDs had 8 tiles and two had 4)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = wave & 3, wq = wave >> 2, t = wq * 64 + lane, d = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x, hd = 128;
+  // to_qkv weights of this wave's tiles (wq and wq + 4 < 6), requested before anything else: lane (d, half) holds W[row][32 kc + 16 half .. + 15]
+  float4 wq0[8], wq1[8];
+  {
+    const float* w0 = qa.W + ((long long)(h * 4 + wq) * 2 * 8 * 64 + lane) * 4;      // fragment order (pack_attn_block_fragments): 1 KB per wave and load
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wq0[j] = *reinterpret_cast<const float4*>(w0 + j * 256);
+    if (wq < 2) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wq1[j] = *reinterpret_cast<const float4*>(w0 + (8 + j) * 256);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wq1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float* sq = hb + h * AB_HEAD_F; float* sk = sq + 64 * AB_QLD; float* sv = sk + 64 * 32; float* ctx = sv + 64 * 32; float* kred = ctx + 32 * 32;
+  typedef float f32x16l __attribute__((ext_vector_type(16)));
+  typedef float f32x4l __attribute__((ext_vector_type(4)));
+  // ---- GroupNorm statistics of the block input from the producer's partials; the input tile: one float4 per thread
+  {
+    double s = 0.0, q = 0.0;
+    for (int i = tid; i < qa.gn_nparts; i += 1024) { const float2 v = qa.gn_part[(long long)i * a.B + b]; s += (double)v.x; q += (double)v.y; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (lane == 0) { sred[wave] = s; sred[16 + wave] = q; }
+    const int p = tid >> 4, c4 = (tid & 15) * 4;
+    *reinterpret_cast<float4*>(ht + p * AB_HT + c4) = *reinterpret_cast<const float4*>(qa.A + ((long long)p * a.B + b) * qa.lda + c4);
+  }
+  __syncthreads();
+  AB_STAMP(1);
+  if (tid == 0) {
+    double ss = 0.0, qq = 0.0;
+    for (int w = 0; w < 16; ++w) { ss += sred[w]; qq += sred[16 + w]; }
+    const double mean = ss * (double)qa.gn_inv;
+    double var = qq * (double)qa.gn_inv - mean * mean; var = var < 0.0 ? 0.0 : var;
+    wstat[32] = (float)mean; wstat[33] = rsqrtf((float)var + 1e-5f);
+  }
+  __syncthreads();
+  AB_STAMP(2);
+  {
+    const float mean = wstat[32], rstd = wstat[33];
+    // ---- q | k | v of head h: 6 tiles of 32 pixels x 32 channels, K = 64; wave wq takes tiles wq and wq + 4
+    for (int tl = wq; tl < 6; tl += 4) {
+      const int nt = tl % 3, mt = tl / 3;                          // nt: 0 q, 1 k, 2 v
+      const int nrow = nt * hd + h * 32 + d;
+      f32x16l acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int kc = 0; kc < 2; ++kc) {
+        float av[16], wv[16];
+        const float* ap = ht + (mt * 32 + d) * AB_HT + kc * 32 + 16 * half;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 x = *reinterpret_cast<const float4*>(ap + 4 * j), w = tl == wq ? wq0[kc * 4 + j] : wq1[kc * 4 + j];
+          av[4 * j] = x.x; av[4 * j + 1] = x.y; av[4 * j + 2] = x.z; av[4 * j + 3] = x.w;
+          wv[4 * j] = w.x; wv[4 * j + 1] = w.y; wv[4 * j + 2] = w.z; wv[4 * j + 3] = w.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], wv[j], acc, 0, 0, 0);
+      }
+      float* dst = nt == 0 ? sq : (nt == 1 ? sk : sv);
+      const float bv = qa.bias ? qa.bias[nrow] : 0.f;
+      const float gs = qa.gn_s[nrow], gb = qa.gn_b1[nrow];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = acc[r] * rstd;
+        v += bv;
+        v += gb - (mean * rstd) * gs;
+        dst[p * (nt == 0 ? AB_QLD : 32) + d] = v;
+      }
+    }
+  }
+  __syncthreads();
+  AB_STAMP(3);
+  // ---- softmax of k over the 64 pixels (kept as exp, the sum divides the context), of q over the 32 channels (x scale): linattn_lds4_kernel's form
+  const int kd = t & 31, kg = t >> 5;
+  float m = -INFINITY;
+  for (int i = kg; i < 64; i += 8) m = fmaxf(m, sk[i * 32 + kd]);
+  kred[kg * 32 + kd] = m;
+  __syncthreads();
+  AB_STAMP(4);
+  float kmax = kred[kd];
+#pragma unroll
+  for (int g = 1; g < 8; ++g) kmax = fmaxf(kmax, kred[g * 32 + kd]);
+  __syncthreads();
+  AB_STAMP(5);
+  float ps = 0.f;
+  for (int i = kg; i < 64; i += 8) { const float e = expf(sk[i * 32 + kd] - kmax); sk[i * 32 + kd] = e; ps += e; }
+  kred[kg * 32 + kd] = ps;
+  {
+    const int qi = t >> 2, part = t & 3;
+    float* qp = sq + qi * AB_QLD + part * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = qp[j];
+    float qm = v[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) qm = fmaxf(qm, v[j]);
+    qm = fmaxf(qm, __shfl_xor(qm, 1)); qm = fmaxf(qm, __shfl_xor(qm, 2));
+    float qsum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = expf(v[j] - qm); qsum += v[j]; }
+    qsum += __shfl_xor(qsum, 1); qsum += __shfl_xor(qsum, 2);
+    const float qf = a.scale / qsum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qp[j] = v[j] * qf;
+  }
+  __syncthreads();
+  AB_STAMP(6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  // to_out.0's weights of this wave's column tile, requested now (used three phases on): lane (n, kq) holds Wo[n][32 kq .. 32 kq + 31] -- the MFMA's k
+  // runs over {32 kq + s}, i.e. lane group kq contracts head kq
+  const int e_pt = wave >> 2, e_nt = wave & 3;
+  float4 wo[8];
+  {
+    const float* wp = ab.Wo + ((long long)e_nt * 8 * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wo[j] = *reinterpret_cast<const float4*>(wp + j * 256);
+  }
+  // ---- context[d][e] = sum_px k~[px][d] v[px][e] / sum_px k~[px][d]: wave wq owns the 16 x 16 tile (di, ej), K = 64 pixels, v_mfma_f32_16x16x4_f32
+  //      (lane (i = lane & 15, kq = lane >> 4): A[i][k = 4 s + kq], B[k][j = lane & 15]; result rows 4 kq + r)
+  {
+    const int di = wq >> 1, ej = wq & 1;
+    f32x4l acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { const int px = 4 * s + kq; acc = __builtin_amdgcn_mfma_f32_16x16x4f32(sk[px * 32 + di * 16 + l15], sv[px * 32 + ej * 16 + l15], acc, 0, 0, 0); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dd = di * 16 + 4 * kq + r;
+      float ks = kred[dd];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) ks += kred[g * 32 + dd];
+      ctx[dd * 32 + ej * 16 + l15] = acc[r] * (1.0f / ks);
+    }
+  }
+  __syncthreads();
+  AB_STAMP(7);
+  // ---- out[px][e] = sum_d q~[px][d] context[d][e]: wave wq owns the 16 pixels of tile wq, both column tiles; the result replaces q~ (rows nobody else reads)
+  {
+    f32x4l o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const float qv = sq[(wq * 16 + l15) * AB_QLD + 4 * s + kq];
+      o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, ctx[(4 * s + kq) * 32 + l15], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(qv, ctx[(4 * s + kq) * 32 + 16 + l15], o1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { float* row = sq + (wq * 16 + 4 * kq + r) * AB_QLD; row[l15] = o0[r]; row[16 + l15] = o1[r]; }
+  }
+  __syncthreads();
+  AB_STAMP(8);
+  // ---- u = to_out.0(att) + bias: wave (e_pt, e_nt) owns a 16 x 16 tile of the 64 x 64 output, K = 128 = 4 heads x 32
+  f32x4l u = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* arow = hb + kq * AB_HEAD_F + (e_pt * 16 + l15) * AB_QLD;      // att[px][32 kq + s] = head kq's tile
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      u = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j], wo[j].x, u, 0, 0, 0);
+      u = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + 1], wo[j].y, u, 0, 0, 0);
+      u = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + 2], wo[j].z, u, 0, 0, 0);
+      u = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * j + 3], wo[j].w, u, 0, 0, 0);
+    }
+  }
+  const int n = e_nt * 16 + l15;
+  {
+    const float bv = ab.bo ? ab.bo[n] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { u[r] += bv; s1 += u[r]; s2 += u[r] * u[r]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) { wstat[2 * wave] = s1; wstat[2 * wave + 1] = s2; }
+  }
+  const float ga = ab.gamma[n], be = ab.beta[n];
+  __syncthreads();
+  AB_STAMP(9);
+  if (tid == 0) {                                                // (fp64 division and square root: one thread, not 1024)
+    double ss = 0.0, qq = 0.0;
+    for (int w = 0; w < 16; ++w) { ss += (double)wstat[2 * w]; qq += (double)wstat[2 * w + 1]; }
+    const double mean_d = ss * (double)ab.inv_count;
+    double var = qq * (double)ab.inv_count - mean_d * mean_d; var = var < 0.0 ? 0.0 : var;
+    wstat[32] = (float)mean_d; wstat[33] = (float)(1.0 / sqrt(var + 1e-5));
+  }
+  __syncthreads();
+  AB_STAMP(10);
+  {
+    const float mean = wstat[32], rstd = wstat[33];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int px = e_pt * 16 + 4 * kq + r;
+      ab.out[((long long)px * a.B + b) * ab.ldo + n] = ((u[r] - mean) * rstd) * ga + be + ht[px * AB_HT + n];
+    }
+  }
+  AB_STAMP(15);
+}
+
 // softmax attention core (unet_model.py:141-148), n <= 64: one wave per (sample, head); lane = query i
 __global__ __launch_bounds__(64) void attn_kernel(const AttnArgs a) {
   __shared__ float sk[32][65], sv[32][65];
@@ -1713,6 +1943,7 @@ static const char* launch_gemm(const GemmOp& o, GemmHot g, const float* ext_in, 
 void prepare_layer_kernels() {
   ensure_dynamic_lds(reinterpret_cast<const void*>(dwconv7_t8_kernel), 64 * 1024);
   ensure_dynamic_lds(reinterpret_cast<const void*>(linattn_lds4_kernel), 3 * 320 * 128);     // + 18 KB static: within the 160 KB of a CU
+  ensure_dynamic_lds(reinterpret_cast<const void*>(attnblock_kernel), AB_LDS_BYTES);
 }
 
 const char* launch_op(const DevPlan& dp, int idx, const float* ext_in, float* ext_out, hipStream_t st) {
@@ -1848,6 +2079,71 @@ const char* launch_qkv_linattn(const DevPlan& dp, int i, hipStream_t st) {
   return nullptr;
 }
 
+// ops i .. i + 3 = to_qkv, LinearAttention core, to_out.0, GroupNorm + residual of an 8x8 attention block with 64 channels and 4 heads:
+// one attnblock_kernel launch (the plan keeps the last two out of the pixel kernel's run for it: plan.cpp attn_block_on)
+bool attn_block_fusable(const Plan& plan, int i) {
+  if (!attn_block_on() || !qkv_linattn_fusable(plan, i) || i + 3 >= (int)plan.ops.size()) return false;
+  const Op& o2 = plan.ops[i + 2]; const Op& o3 = plan.ops[i + 3];
+  if (o2.kind != OP_GEMM || o3.kind != OP_GN_RES || o2.chain || o2.row || o3.chain || o3.row) return false;
+  const GemmOp& q = plan.ops[i].g; const AttnOp& t = plan.ops[i + 1].at; const GemmOp& g = o2.g; const GnResOp& r = o3.gr;
+  if (t.heads != 4 || q.Npad != 384 || q.a.C != 64) return false;
+  if (g.Hout * g.Wout != 64 || g.KH != 1 || g.KW != 1 || g.Kp != 128 || g.Npad != 64 || g.N > 64 || g.gn || g.has2 || g.has_res || g.act != ACT_NONE || g.a_ext || g.out_nchw) return false;
+  if (g.up != 1 || g.stride != 1 || g.w_pix_stride || g.bias_pix_stride || g.stat_off < 0 || g.a.off != t.out.off || g.a.H * g.a.W != 64) return false;
+  if (r.out_ext || r.u.off != g.out.off || r.part_off != g.stat_off || r.x.off != q.a.off || r.x.ld != q.a.ld || r.u.C != 64 || r.u.H * r.u.W != 64) return false;
+  return true;
+}
+
+// The block's weights in the order its lanes read them, so that every wave-level load is 1 KB contiguous (as packed [n][k] matrices a wave's
+// float4 load touched 32 rows 256 B apart: the first barrier of the kernel came 6.4 us after its start, mostly waiting for the TA).
+//   to_qkv : [head h][quarter wq][slot: tile wq | tile wq + 4][j = 0 .. 7][lane = 32 half + d][4] = W[(tile % 3) 128 + 32 h + d][32 (j >> 2) + 16 half + 4 (j & 3) ..]
+//   to_out.0: [column tile nt][j = 0 .. 7][lane = 16 kq + l][4] = Wo[16 nt + l][32 kq + 4 j ..]
+void pack_attn_block_fragments(Plan* plan, int i) {
+  GemmOp& g = plan->ops[i].g; GemmOp& go = plan->ops[i + 2].g;
+  std::vector<float> fq((size_t)4 * 4 * 2 * 8 * 64 * 4, 0.f), fo((size_t)4 * 8 * 64 * 4, 0.f);
+  const float* W = plan->params.data() + g.w_off; const float* Wo = plan->params.data() + go.w_off;
+  for (int h = 0; h < 4; ++h) for (int wq = 0; wq < 4; ++wq) for (int slot = 0; slot < 2; ++slot) {
+    const int tl = wq + 4 * slot;
+    if (tl >= 6) continue;
+    for (int j = 0; j < 8; ++j) for (int lane = 0; lane < 64; ++lane) {
+      const int d = lane & 31, half = lane >> 5, nrow = (tl % 3) * 128 + h * 32 + d, k = 32 * (j >> 2) + 16 * half + 4 * (j & 3);
+      memcpy(&fq[((((size_t)(h * 4 + wq) * 2 + slot) * 8 + j) * 64 + lane) * 4], W + (size_t)nrow * 64 + k, 16);
+    }
+  }
+  for (int nt = 0; nt < 4; ++nt) for (int j = 0; j < 8; ++j) for (int lane = 0; lane < 64; ++lane) {
+    const int l = lane & 15, kq = lane >> 4;
+    memcpy(&fo[(((size_t)nt * 8 + j) * 64 + lane) * 4], Wo + (size_t)(16 * nt + l) * 128 + 32 * kq + 4 * j, 16);
+  }
+  auto append = [&](const std::vector<float>& v) { while (plan->params.size() & 3) plan->params.push_back(0.f); const int64_t off = (int64_t)plan->params.size(); plan->params.insert(plan->params.end(), v.begin(), v.end()); return off; };
+  g.wt_off = append(fq); go.wt_off = append(fo);
+}
+
+const char* launch_attn_block(const DevPlan& dp, int i, hipStream_t st) {
+  const Plan& plan = *dp.plan; const GemmOp& g = plan.ops[i].g; const AttnOp& t = plan.ops[i + 1].at; const GemmOp& go = plan.ops[i + 2].g; const GnResOp& r = plan.ops[i + 3].gr;
+  AttnBlockArgs ab{};
+  QkvAttnArgs& q = ab.q;
+  q.a = make_attn_args(t, dp.ws);
+  q.A = dp.ws + g.a.off; q.lda = g.a.ld; q.W = dp.prm + g.w_off; q.bias = g.bias_off >= 0 ? dp.prm + g.bias_off : nullptr;
+  q.gn_part = reinterpret_cast<const float2*>(dp.ws + g.gn_part_off); q.gn_nparts = g.gn_nparts; q.gn_inv = g.gn_inv_count;
+  q.gn_s = dp.prm + g.gn_s_off; q.gn_b1 = dp.prm + g.gn_b1_off; q.Npad = g.Npad;
+  if (g.wt_off < 0 || go.wt_off < 0) return "attention block: no fragment-order weights (model creation packs them)";
+  q.W = dp.prm + g.wt_off;
+  ab.Wo = dp.prm + go.wt_off; ab.bo = go.bias_off >= 0 ? dp.prm + go.bias_off : nullptr;
+  ab.gamma = dp.prm + r.gamma_off; ab.beta = dp.prm + r.beta_off;
+  ab.out = dp.ws + r.out.off; ab.ldo = r.out.ld; ab.inv_count = r.inv_count;
+  static unsigned long long* d_dbg = [] { unsigned long long* p = nullptr; if (std::getenv("SBM_ATTNBLOCK_STAMPS")) (void)hipMalloc(&p, 16 * sizeof(unsigned long long)); return p; }();
+  ab.dbg = d_dbg;
+  SBM_KLAUNCH(attnblock_kernel, dim3(t.B), dim3(1024), AB_LDS_BYTES, st, ab);
+  if (d_dbg) {                                                   // diagnostics only (synchronises: not under stream capture)
+    unsigned long long hbuf[16];
+    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(hbuf, d_dbg, sizeof(hbuf), hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "attnblock stamps (s_memtime at ~2.1 GHz):");
+      for (int i = 1; i < 16; ++i) if (hbuf[i]) fprintf(stderr, " [%d] %.2f us", i, (double)(hbuf[i] - hbuf[0]) / 2100.0);
+      fprintf(stderr, "\n");
+    }
+  }
+  return nullptr;
+}
+
 const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops) {
   const Plan& plan = *dp.plan;
   if (plan.time_off >= 0 && t_dev && t_dev != dp.ws + plan.time_off)
@@ -1861,7 +2157,13 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
     int n = 1;
     const char* e;
     if (skipped(i)) { ++i; continue; }
-    if (plan.ops[i].fuse_next) {                    // to_qkv + LinearAttention core as one kernel
+    if (plan.ops[i].fuse_next == 2) {               // a whole 8x8 attention block (four ops) as one kernel
+      e = launch_attn_block(dp, i, st);
+      if (e) return e;
+      i += 4;
+      continue;
+    }
+    if (plan.ops[i].fuse_next == 1) {               // to_qkv + LinearAttention core as one kernel
       e = launch_qkv_linattn(dp, i, st);
       if (e) return e;
       i += 2;

@@ -344,8 +344,17 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tid0 = tid;
   const int b = blockIdx.x;
+  // a run that begins with init_conv's im2col: the sample's row-packed image (written by the previous step's update kernel, so a trip to memory)
+  // is requested before the LDS is cleared and lands in scr under it
+  const bool stage0 = ldc(&ops[0].kind) == OP_IM2COL;
+  float4 pre0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (stage0) {
+    const int ld = ldc(&ops[0].st_ld);
+    if (tid < 2 * ld) pre0 = *reinterpret_cast<const float4*>(ldc(&ops[0].st_src) + ((long long)(tid / (ld >> 2)) * B + b) * ld + 4 * (tid % (ld >> 2)));
+  }
   for (int i = tid; i < act_floats + P_RED_F; i += PNT) lds[i] = 0.f;
   for (int i = tid; i < nrowtab * 16; i += PNT) rtab[i] = rowtab[i];
+  if (stage0 && tid < 2 * ldc(&ops[0].st_ld)) *reinterpret_cast<float4*>(scr + 4 * tid) = pre0;
   // the time conditions of the depth-wise ops: the step's row of the sampler's table, resolved once per launch
   const float* cond_tab = nullptr;
   if (ctl && ctl->table_mode) cond_tab = ctl->table + (long long)ctl->step * ctl->tab_ld;
@@ -439,6 +448,41 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       __syncthreads();
       continue;
     }
+    if (kind == OP_IM2COL) {
+      // init_conv's input matrix: the sample's row-packed image (8 rows of st_ld floats, element (y, x, c) at x * Cpad + c) goes through scr,
+      // then thread (k, pixel parity) writes column k = c * 49 + ky * 7 + kx of every other pixel: source (oy + ky - 3, ox + kx - 3) or zero
+      int tid = tid0; asm volatile("" : "+v"(tid));
+      const int ld = ldc(&op.st_ld), C = ldc(&op.st_C), Cpad = ldc(&op.st_P), Kld = ldc(&op.st_nparts), out_lds = ldc(&op.out_lds), out_sub = ldc(&op.out_sub);
+      const float* src = ldc(&op.st_src);
+      float* gout = ldc(&op.out_g) ? const_cast<float*>(reinterpret_cast<const float*>(ldc(&op.st_part))) : nullptr;
+      if (k != 0 || !stage0) {                              // (the first op of a run: staged by the kernel's prologue; needs 2 ld <= 512 threads)
+        for (int i = tid; i < 2 * ld; i += PNT) *reinterpret_cast<float4*>(scr + 4 * i) = *reinterpret_cast<const float4*>(src + ((long long)(i / (ld >> 2)) * B + b) * ld + 4 * (i % (ld >> 2)));
+        __syncthreads();
+      }
+      // thread = (four consecutive columns k, output column ox = its wave): the (c, ky, kx) of its columns and their horizontal validity are fixed,
+      // the loop runs over the eight output rows -- four LDS reads and one 16-byte store per pixel
+      const int k4 = (tid & 63) * 4, ox = tid >> 6;
+      int sofs[4], kyo[4]; bool cok[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k4 + j, c = kk / 49, r = kk - 49 * c, ky = r / 7, kx = r - 7 * ky, ix = ox + kx - 3;
+        cok[j] = c < C && (unsigned)ix < 8u; kyo[j] = ky - 3; sofs[j] = (ky - 3) * ld + ix * Cpad + c;
+      }
+      float* dp_ = lds + out_lds + (k4 >> 4) * PCS + (k4 & 15);
+#pragma unroll
+      for (int oy = 0; oy < 8; ++oy) {
+        const int p = oy * 8 + ox;
+        float4 v;
+        v.x = (cok[0] && (unsigned)(oy + kyo[0]) < 8u) ? scr[sofs[0] + oy * ld] : 0.f;
+        v.y = (cok[1] && (unsigned)(oy + kyo[1]) < 8u) ? scr[sofs[1] + oy * ld] : 0.f;
+        v.z = (cok[2] && (unsigned)(oy + kyo[2]) < 8u) ? scr[sofs[2] + oy * ld] : 0.f;
+        v.w = (cok[3] && (unsigned)(oy + kyo[3]) < 8u) ? scr[sofs[3] + oy * ld] : 0.f;
+        *reinterpret_cast<float4*>(dp_ + (p >> 4) * out_sub + (p & 15) * 16) = v;
+        if (gout) *reinterpret_cast<float4*>(gout + ((long long)p * B + b) * Kld + k4) = v;
+      }
+      __syncthreads();
+      continue;
+    }
     if (kind == OP_DWCONV7) {
       int tid = tid0; asm volatile("" : "+v"(tid));
       const int lane = tid & 63;
@@ -469,11 +513,10 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
 #pragma unroll 1                                           // one window row at a time: unrolled, the seven rows' operands push the kernel past 128 VGPRs (AGPR spills)
           for (int ky = 0; ky < 7; ++ky) {
             const int qy = py + ky - 3;
-            const bool in = qy >= 0 && qy < 8;
-            const int qyc = in ? qy : 0;
+            if (qy < 0 || qy >= 8) continue;                 // a window row outside the image (21 % of them): a wave holds two output rows, so most of these skips are wave-uniform
             sbm_f32x2 xr[8], wr[7];
 #pragma unroll
-            for (int qx = 0; qx < 8; ++qx) { const sbm_f32x2 v = *reinterpret_cast<const sbm_f32x2*>(lds + in_lds + pix_at2(c, qyc * 8 + qx, in_sub)); xr[qx] = in ? v : (sbm_f32x2){0.f, 0.f}; }
+            for (int qx = 0; qx < 8; ++qx) xr[qx] = *reinterpret_cast<const sbm_f32x2*>(lds + in_lds + pix_at2(c, qy * 8 + qx, in_sub));
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) wr[kx] = *reinterpret_cast<const sbm_f32x2*>(scr + (ky * 7 + kx) * C + c);
 #pragma unroll
@@ -1195,6 +1238,7 @@ struct PBuilder {
       else if (o.kind == OP_DWCONV7) { look(o.dw.in); look(o.dw.out); }
       else if (o.kind == OP_GN_RES) { look(o.gr.u); look(o.gr.x); look(o.gr.out); }
       else if (o.kind == OP_LINATTN) { look(o.at.qkv); look(o.at.out); }
+      else if (o.kind == OP_IM2COL) { look(o.ic.out); }
     }
     PSlot s{base, v.ld, P, act_chunks * PCS, (int)ops.size(), (int)ops.size()};
     if (v.ld & 15) err = "pixel kernel: a tensor's channel pitch is not a multiple of 16";
@@ -1224,6 +1268,7 @@ struct PBuilder {
     else if (o.kind == OP_DWCONV7) { rd->push_back(&o.dw.in); wr->push_back(&o.dw.out); }
     else if (o.kind == OP_GN_RES) { rd->push_back(&o.gr.u); rd->push_back(&o.gr.x); wr->push_back(&o.gr.out); }
     else if (o.kind == OP_LINATTN || o.kind == OP_ATTN) { rd->push_back(&o.at.qkv); wr->push_back(&o.at.out); }
+    else if (o.kind == OP_IM2COL) { wr->push_back(&o.ic.out); }      // (its input is the row-packed tensor in memory: never a slab)
   }
   // Op `cur` writes the channels [v.off, v.off + v.C) of slot si and nothing of the slot has been produced yet.  True when every channel of
   // the slot OUTSIDE that range is written by a later op of this run before any op of the run reads it (the two halves of a skip
@@ -1312,6 +1357,13 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         d.in_lds = b.need(o.qkv);
         d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out, i);
         d.at = make_attn_args(o, dp.ws);
+      } else if (op.kind == OP_IM2COL) {
+        const Im2colOp& o = op.ic;
+        if (o.H != 8 || o.W != 8 || o.KH != 7 || o.KW != 7 || o.pad != 3 || o.H * o.in.ld > P_SCR_F || 2 * o.in.ld > PNT || (o.in.ld & 3) || o.C * 49 > o.out.ld || o.out.ld != 256) return "pixel kernel: im2col outside the supported shapes";
+        d.st_src = dp.ws + o.in.off; d.st_ld = o.in.ld; d.st_C = o.C; d.st_P = o.Cpad; d.st_nparts = o.out.ld;
+        d.out_lds = b.slab(o.out, nullptr); b.mark_produced(o.out, i); d.out_sub = PBuilder::sub_floats(o.out.ld);
+        d.st_lds = d.out_lds; d.st_stat = o.out.ld;            // (st_stat: the pitch of the workspace copy)
+        d.st_part = reinterpret_cast<const float2*>(dp.ws + o.out.off);      // (st_part: the workspace copy itself, written when out_g is set)
       } else if (op.kind == OP_GEMM) {
         const GemmOp& g = op.g;
         if (const char* e = pix_gemm_supported(g)) return e;
@@ -1484,9 +1536,10 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
           if (o.kind == OP_DWCONV7) return hit(o.dw.in);
           if (o.kind == OP_GN_RES) return hit(o.gr.u) || hit(o.gr.x);
           if (o.kind == OP_LINATTN || o.kind == OP_ATTN) return hit(o.at.qkv);
+          if (o.kind == OP_IM2COL) return hit(o.ic.in);
           return true;                                   // any other kind: assume it reads everything
         };
-        const View* outv = op.kind == OP_GEMM ? &op.g.out : (op.kind == OP_DWCONV7 ? &op.dw.out : (op.kind == OP_GN_RES ? &op.gr.out : &op.at.out));
+        const View* outv = op.kind == OP_GEMM ? &op.g.out : (op.kind == OP_DWCONV7 ? &op.dw.out : (op.kind == OP_GN_RES ? &op.gr.out : (op.kind == OP_IM2COL ? &op.ic.out : &op.at.out)));
         bool outside = i == (int)plan.ops.size() - 1;
         for (int j = 0; j < (int)plan.ops.size() && !outside; ++j) if ((j < first || j >= first + count) && j > i && reads(plan.ops[j], *outv)) outside = true;
         long long soff = op.kind == OP_GEMM ? op.g.stat_off : (op.kind == OP_DWCONV7 ? op.dw.stat_off : -1);

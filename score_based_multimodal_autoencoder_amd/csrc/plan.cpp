@@ -187,6 +187,7 @@ std::vector<TensorSpec> attrdec_tensor_specs(const AttrDecCfg& c) {
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+bool attn_block_on_impl() { const char* e = std::getenv("SBM_ATTN_BLOCK"); return !(e && std::atoi(e) == 0); }
 // pixel mode: the first and the last conv of a score net inside the sample-owned kernel (read when a plan is built)
 bool pix_io_on() { const char* e = std::getenv("SBM_PIX_IO"); return !(e && std::atoi(e) == 0); }
 
@@ -641,7 +642,10 @@ View emit_attention(Builder& b, const std::string& pre, const View& x, int c, in
     b.plan->flops_exec += 2.0 * b.B * 4 * (linear ? 2.0 * 32 * 32 * P : 2.0 * 32 * (double)P * P);
   }
   b.free_act(rq.out);
-  b.chain_pix = attn_saved_chain_pix;
+  // ... and an 8x8 block of 64 channels and 4 heads runs WHOLE in one kernel (kernels.hip attnblock_kernel; marked at model creation by
+  // attn_block_fusable): its to_out.0 and GroupNorm + residual then stay out of the pixel kernel's run too
+  const bool whole_block = b.pix_mode && linear && P == 64 && c == 64 && hid == 128 && attn_block_on_impl();
+  if (!whole_block) b.chain_pix = attn_saved_chain_pix;
   View out;
   if (linear) {
     Builder::ConvSpec o;
@@ -658,6 +662,7 @@ View emit_attention(Builder& b, const std::string& pre, const View& x, int c, in
     g.gamma_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.weight", c), c, nullptr, x.C));
     g.beta_off = b.add_params(b.pack_vec(b.T(pre + "fn.fn.to_out.1.bias", c), c, nullptr, x.C));
     b.ws_free(ro.stat_off); b.free_act(ro.out);
+    b.chain_pix = attn_saved_chain_pix;
   } else {
     Builder::ConvSpec o;
     o.name = pre + "fn.fn.to_out"; o.a = att; o.cm = ChanMap::identity(hid); o.cin_true = hid;
@@ -675,6 +680,7 @@ int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
 
 static thread_local int g_plan_pix_mode = 0;
 void plan_set_pix_mode(int mode) { g_plan_pix_mode = mode; }
+bool attn_block_on() { return attn_block_on_impl(); }
 int plan_pix_mode() { return g_plan_pix_mode; }
 
 int chain_pix_from_env(int B) {
@@ -792,6 +798,9 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
     const int rowK = round_up(Wp * 8, 32);
     const bool rowpack = cfg.channels <= 8 && !std::getenv("SBM_NO_ROWPACK") &&
                          (int64_t)Hp * Wp * 7 * round_up(pad8(d.init_dim), 32) * rowK * 4 <= (16LL << 20);
+    // pixel mode, 8x8 inputs: init_conv INSIDE the first run of the sample-owned kernel -- the row-packed input is expanded in LDS to the
+    // [64 pixels][C * 49] matrix and the 7x7 conv is a 1x1 conv over it (K = 245 -> 256 for 5 modalities: 8 K steps instead of a launch)
+    const bool im2col = rowpack && b.pix_mode && pix_io_on() && Hp == 8 && Wp == 8 && b.chain_pix >= 64 && cfg.channels * 49 <= 256;
     if (rowpack) {
       Op& cv = plan->ops[0];                                   // the input conversion emitted above
       View rows; rows.H = Hp; rows.W = 1; rows.C = Wp * 8; rows.ld = rowK;
@@ -799,11 +808,25 @@ bool build_unet_plan(const UnetCfg& cfg, int B, const float* const* tensors, Pla
       rows.off = b.ws_alloc((int64_t)Hp * B * rows.ld, true);     // pinned: the sampler's update kernels keep it current between forwards (sampler.hip store_pbc), so nothing else may recycle it
       cv.cv.out = rows; cv.cv.rowpack = 1; cv.cv.Wo = Wp; cv.cv.Cpad = 8;
       xin = rows;
+    }
+    if (im2col) {
+      const int K = cfg.channels * 49;
+      View col; col.H = Hp; col.W = Wp; col.C = pad8(K); col.ld = 256;      // the expansion's thread mapping (pixrun.hip OP_IM2COL): 64 lanes x 4 columns
+      col.off = b.ws_alloc((int64_t)Hp * Wp * B * col.ld, true);
+      Op& op = b.push(OP_IM2COL, "init_conv im2col");
+      op.chain = 1;
+      Im2colOp& ic = op.ic; ic.B = B; ic.in = xin; ic.out = col; ic.C = cfg.channels; ic.Cpad = 8; ic.H = Hp; ic.W = Wp; ic.KH = ic.KW = 7; ic.pad = 3;
+      Builder::ConvSpec cs; cs.name = "init_conv (1x1 over im2col)"; cs.a = col; cs.cm = ChanMap::identity(K); cs.cin_true = K;
+      cs.w = b.T("init_conv.weight", (int64_t)d.init_dim * K); cs.bias = b.T("init_conv.bias", d.init_dim);
+      cs.cout = d.init_dim; cs.Hout = Hp; cs.Wout = Wp;
+      x = b.emit_conv(cs).out;
+      b.ws_free(col.off);
+    } else if (rowpack) {
       const float* w = b.T("init_conv.weight", (int64_t)d.init_dim * cfg.channels * 49); const float* bi = b.T("init_conv.bias", d.init_dim);
       const int P = Hp * Wp, cout = d.init_dim;
       x = b.new_act(Hp, Wp, cout);
       Op& op = b.push(OP_GEMM, "init_conv (row-packed)");
-      GemmOp& g = op.g; g.B = B; g.Hout = Hp; g.Wout = Wp; g.a = rows; g.a_rows = 1; g.KH = 7; g.KW = 1; g.stride = 1; g.pad = 3;
+      GemmOp& g = op.g; g.B = B; g.Hout = Hp; g.Wout = Wp; g.a = xin; g.a_rows = 1; g.KH = 7; g.KW = 1; g.stride = 1; g.pad = 3;
       g.N = cout; g.Npad = round_up(pad8(cout), 32); g.Kp = rowK; g.out = x;
       std::vector<float> wp((size_t)P * 7 * g.Npad * g.Kp, 0.f), bp(g.Npad, 0.f);
       for (int pp = 0; pp < P; ++pp) {

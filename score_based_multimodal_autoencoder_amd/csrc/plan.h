@@ -35,6 +35,7 @@ enum OpKind : int {
   OP_GN32 = 9,        // GroupNorm(G, C) (+ SiLU) materialised: unet_openai normalization()
   OP_ATTN_QKV = 10,   // unet_openai QKVAttention core (softmax over T tokens, any head width)
   OP_AVGPOOL = 12,    // AvgPool2d(k) PBC -> PBC (encoders); 11 is the profiling bucket of the chain kernel
+  OP_IM2COL = 15,     // pixel mode only: the row-packed input of a score net -> the [pixel][C KH KW] matrix init_conv multiplies as a 1x1 conv (13, 14: profiling buckets)
 };
 
 // A view of an activation tensor inside the workspace arena.
@@ -142,6 +143,9 @@ struct CvtOp {
 
 struct BilinearOp { int B = 0; int scale = 2; View in, out; };
 
+// in: the row-packed input (CvtOp::rowpack: H rows of W * Cpad channels); out: [H W pixels][k = c * KH * KW + ky * KW + kx], zero outside the image and for k >= C KH KW
+struct Im2colOp { int B = 0; View in, out; int C = 0, Cpad = 0, H = 0, W = 0, KH = 0, KW = 0, pad = 0; };
+
 struct GnFinalOp { int B = 0; int64_t part_off = 0; int nparts = 0; int64_t out_off = 0; };
 
 struct Op {
@@ -149,11 +153,12 @@ struct Op {
   std::string name;       // reference layer this op implements (for profiles and error messages)
   double flops = 0;       // 2*MAC this op issues (padding taps skipped, channel padding included)
   double flops_dense = 0; // GEMM ops: 2*MAC in the dense convention (zero-padding taps counted), the roofline numerator
-  int fuse_next = 0;      // 1 (set at model creation): this to_qkv GEMM and the LinearAttention core behind it run as one kernel
+  int fuse_next = 0;      // set at model creation.  1: this to_qkv GEMM and the LinearAttention core behind it run as one kernel; 2: so do the to_out.0
+                          // GEMM and the GroupNorm + residual behind those (attnblock_kernel), which carry -1
   int time_path = 0;      // 1: depends on the time input only (sinusoid, time MLP, per-block condition GEMM): the sampler tabulates it
   int chain = 0;          // 1: runs inside the XCD-resident chain kernel (low-resolution ops; GEMM tile 32x32) -- chain.hip
   int row = 0;            // 1: runs inside the row kernel (the one-position level, four samples per workgroup, LDS-resident) -- rowrun.hip
-  GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf; Gn32Op gn; AttnQkvOp aq;
+  GemmOp g; DwOp dw; AttnOp at; GnResOp gr; SinusOp si; CvtOp cv; BilinearOp bl; GnFinalOp gf; Gn32Op gn; AttnQkvOp aq; Im2colOp ic;
 };
 
 struct ChunkDesc { int a_off, w_off, gkc, flags; };
@@ -194,6 +199,8 @@ int row_pix_from_env();
 // How the next build_unet_plan of this thread marks the low-resolution ops: 0 legacy (chain kernel + row kernel, batch-size gated),
 // 1 pixel mode (sample-owned kernel, pixrun.hip: every batch size, the one-position level included, time path per-layer).
 void plan_set_pix_mode(int mode);
+bool attn_block_on();   // SBM_ATTN_BLOCK=0 (read when a plan is built and when a model is created): the 8x8 attention block stays to_qkv + core as one kernel,
+                        // to_out.0 and GroupNorm + residual in the pixel kernel's run; default: the whole block is one kernel (kernels.hip attnblock_kernel)
 int plan_pix_mode();
 
 struct UnetCfg {

@@ -30,7 +30,7 @@ while i < n:
         runs.append((i, j)); i = j + 1
     else:
         i += 1
-KN = {0: "gemm", 1: "dw", 2: "linattn", 4: "gn_res", 101: "(stage)", 102: "vec"}
+KN = {0: "gemm", 1: "dw", 2: "linattn", 4: "gn_res", 101: "(stage)", 102: "vec", 15: "im2col"}
 CLK = float(os.environ.get("PIX_CLOCK_MHZ", "2100"))          # s_memtime counts shader cycles; the clock under this load is ~2.1 GHz
 for first, last in runs:
     _lib.check(L.sbm_debug_pix_stamps(eng.h, first, last - first + 1, st, kinds, CAP, ctypes.byref(nout)))
