@@ -1169,6 +1169,9 @@ struct AttnBlockArgs {
   unsigned long long* dbg;                // SBM_ATTNBLOCK_STAMPS=1: s_memtime of workgroup 0 at the phase boundaries
 };
 #define AB_STAMP(i) do { if (ab.dbg && blockIdx.x == 0 && threadIdx.x == 0) ab.dbg[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// a workgroup barrier that waits for this wave's LDS traffic only: __syncthreads() also drains the vector-memory queue, i.e. it would wait for
+// to_out.0's weights at the first barrier behind their request instead of five barriers later
+__device__ __forceinline__ void ab_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 constexpr int AB_QLD = 33, AB_HT = 68;
 constexpr int AB_HEAD_F = 64 * AB_QLD + 64 * 32 + 64 * 32 + 32 * 32 + 8 * 32;      // sq | sk | sv | ctx | kred
 constexpr int AB_LDS_F = 64 * AB_HT + 4 * AB_HEAD_F + 64;
@@ -1186,19 +1189,17 @@ __global__ __launch_bounds__(1024) void attnblock_kernel(const AttnBlockArgs ab)
   // 2 + 2 + 1 + 1 of the 24 to_qkv tiles (with the quarters of one head on four SIMDs, two SIMDs had 8 tiles and two had 4)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = wave & 3, wq = wave >> 2, t = wq * 64 + lane, d = lane & 31, half = lane >> 5;
   const int b = blockIdx.x, hd = 128;
-  // to_qkv weights of this wave's tiles (wq and wq + 4 < 6), requested before anything else: lane (d, half) holds W[row][32 kc + 16 half .. + 15]
-  float4 wq0[8], wq1[8];
-  {
-    const float* w0 = qa.W + ((long long)(h * 4 + wq) * 2 * 8 * 64 + lane) * 4;      // fragment order (pack_attn_block_fragments): 1 KB per wave and load
+  // to_qkv: quarter wq < 3 computes q (0), k (1) or v (2) of its head for BOTH halves of the pixels -- two tiles with the same 32 weight rows, requested
+  // before anything else: lane (d, half) holds W[row][32 kc + 16 half .. + 15].  (Quarter 3 idles here: the SIMD's matrix pipe is the limit, and its
+  // four quarters together have the head's six tiles whichever way they are dealt.)
+  float4 wq0[8];
+  if (wq < 3) {
+    const float* w0 = qa.W + ((long long)(h * 3 + wq) * 8 * 64 + lane) * 4;      // fragment order (pack_attn_block_fragments): 1 KB per wave and load
 #pragma unroll
     for (int j = 0; j < 8; ++j) wq0[j] = *reinterpret_cast<const float4*>(w0 + j * 256);
-    if (wq < 2) {
+  } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) wq1[j] = *reinterpret_cast<const float4*>(w0 + (8 + j) * 256);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wq1[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int j = 0; j < 8; ++j) wq0[j] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float* sq = hb + h * AB_HEAD_F; float* sk = sq + 64 * AB_QLD; float* sv = sk + 64 * 32; float* ctx = sv + 64 * 32; float* kred = ctx + 32 * 32;
   typedef float f32x16l __attribute__((ext_vector_type(16)));
@@ -1226,9 +1227,10 @@ __global__ __launch_bounds__(1024) void attnblock_kernel(const AttnBlockArgs ab)
   AB_STAMP(2);
   {
     const float mean = wstat[32], rstd = wstat[33];
-    // ---- q | k | v of head h: 6 tiles of 32 pixels x 32 channels, K = 64; wave wq takes tiles wq and wq + 4
-    for (int tl = wq; tl < 6; tl += 4) {
-      const int nt = tl % 3, mt = tl / 3;                          // nt: 0 q, 1 k, 2 v
+    // ---- q | k | v of head h: 6 tiles of 32 pixels x 32 channels, K = 64
+    if (wq < 3)
+    for (int mt = 0; mt < 2; ++mt) {
+      const int nt = wq;                                           // nt: 0 q, 1 k, 2 v
       const int nrow = nt * hd + h * 32 + d;
       f32x16l acc;
 #pragma unroll
@@ -1239,7 +1241,7 @@ __global__ __launch_bounds__(1024) void attnblock_kernel(const AttnBlockArgs ab)
         const float* ap = ht + (mt * 32 + d) * AB_HT + kc * 32 + 16 * half;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const float4 x = *reinterpret_cast<const float4*>(ap + 4 * j), w = tl == wq ? wq0[kc * 4 + j] : wq1[kc * 4 + j];
+          const float4 x = *reinterpret_cast<const float4*>(ap + 4 * j), w = wq0[kc * 4 + j];
           av[4 * j] = x.x; av[4 * j + 1] = x.y; av[4 * j + 2] = x.z; av[4 * j + 3] = x.w;
           wv[4 * j] = w.x; wv[4 * j + 1] = w.y; wv[4 * j + 2] = w.z; wv[4 * j + 3] = w.w;
         }
@@ -1261,17 +1263,27 @@ __global__ __launch_bounds__(1024) void attnblock_kernel(const AttnBlockArgs ab)
   }
   __syncthreads();
   AB_STAMP(3);
+  const int l15 = lane & 15, kq = lane >> 4;
+  // to_out.0's weights of this wave's column tile, requested here, behind to_qkv (used five barriers on): lane (n, kq) holds Wo[n][32 kq .. 32 kq + 31] -- the MFMA's k
+  // runs over {32 kq + s}, i.e. lane group kq contracts head kq
+  const int e_pt = wave >> 2, e_nt = wave & 3;
+  float4 wo[8];
+  {
+    const float* wp = ab.Wo + ((long long)e_nt * 8 * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wo[j] = *reinterpret_cast<const float4*>(wp + j * 256);
+  }
   // ---- softmax of k over the 64 pixels (kept as exp, the sum divides the context), of q over the 32 channels (x scale): linattn_lds4_kernel's form
   const int kd = t & 31, kg = t >> 5;
   float m = -INFINITY;
   for (int i = kg; i < 64; i += 8) m = fmaxf(m, sk[i * 32 + kd]);
   kred[kg * 32 + kd] = m;
-  __syncthreads();
+  ab_sync();
   AB_STAMP(4);
   float kmax = kred[kd];
 #pragma unroll
   for (int g = 1; g < 8; ++g) kmax = fmaxf(kmax, kred[g * 32 + kd]);
-  __syncthreads();
+  ab_sync();
   AB_STAMP(5);
   float ps = 0.f;
   for (int i = kg; i < 64; i += 8) { const float e = expf(sk[i * 32 + kd] - kmax); sk[i * 32 + kd] = e; ps += e; }
@@ -1294,18 +1306,8 @@ __global__ __launch_bounds__(1024) void attnblock_kernel(const AttnBlockArgs ab)
 #pragma unroll
     for (int j = 0; j < 8; ++j) qp[j] = v[j] * qf;
   }
-  __syncthreads();
+  ab_sync();
   AB_STAMP(6);
-  const int l15 = lane & 15, kq = lane >> 4;
-  // to_out.0's weights of this wave's column tile, requested now (used three phases on): lane (n, kq) holds Wo[n][32 kq .. 32 kq + 31] -- the MFMA's k
-  // runs over {32 kq + s}, i.e. lane group kq contracts head kq
-  const int e_pt = wave >> 2, e_nt = wave & 3;
-  float4 wo[8];
-  {
-    const float* wp = ab.Wo + ((long long)e_nt * 8 * 64 + lane) * 4;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wo[j] = *reinterpret_cast<const float4*>(wp + j * 256);
-  }
   // ---- context[d][e] = sum_px k~[px][d] v[px][e] / sum_px k~[px][d]: wave wq owns the 16 x 16 tile (di, ej), K = 64 pixels, v_mfma_f32_16x16x4_f32
   //      (lane (i = lane & 15, kq = lane >> 4): A[i][k = 4 s + kq], B[k][j = lane & 15]; result rows 4 kq + r)
   {
@@ -1322,7 +1324,7 @@ __global__ __launch_bounds__(1024) void attnblock_kernel(const AttnBlockArgs ab)
       ctx[dd * 32 + ej * 16 + l15] = acc[r] * (1.0f / ks);
     }
   }
-  __syncthreads();
+  ab_sync();
   AB_STAMP(7);
   // ---- out[px][e] = sum_d q~[px][d] context[d][e]: wave wq owns the 16 pixels of tile wq, both column tiles; the result replaces q~ (rows nobody else reads)
   {
@@ -1336,7 +1338,7 @@ __global__ __launch_bounds__(1024) void attnblock_kernel(const AttnBlockArgs ab)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { float* row = sq + (wq * 16 + 4 * kq + r) * AB_QLD; row[l15] = o0[r]; row[16 + l15] = o1[r]; }
   }
-  __syncthreads();
+  ab_sync();
   AB_STAMP(8);
   // ---- u = to_out.0(att) + bias: wave (e_pt, e_nt) owns a 16 x 16 tile of the 64 x 64 output, K = 128 = 4 heads x 32
   f32x4l u = {0.f, 0.f, 0.f, 0.f};
@@ -2095,20 +2097,17 @@ bool attn_block_fusable(const Plan& plan, int i) {
 
 // The block's weights in the order its lanes read them, so that every wave-level load is 1 KB contiguous (as packed [n][k] matrices a wave's
 // float4 load touched 32 rows 256 B apart: the first barrier of the kernel came 6.4 us after its start, mostly waiting for the TA).
-//   to_qkv : [head h][quarter wq][slot: tile wq | tile wq + 4][j = 0 .. 7][lane = 32 half + d][4] = W[(tile % 3) 128 + 32 h + d][32 (j >> 2) + 16 half + 4 (j & 3) ..]
+//   to_qkv : [head h][nt: q | k | v][j = 0 .. 7][lane = 32 half + d][4] = W[128 nt + 32 h + d][32 (j >> 2) + 16 half + 4 (j & 3) ..]
 //   to_out.0: [column tile nt][j = 0 .. 7][lane = 16 kq + l][4] = Wo[16 nt + l][32 kq + 4 j ..]
 void pack_attn_block_fragments(Plan* plan, int i) {
   GemmOp& g = plan->ops[i].g; GemmOp& go = plan->ops[i + 2].g;
-  std::vector<float> fq((size_t)4 * 4 * 2 * 8 * 64 * 4, 0.f), fo((size_t)4 * 8 * 64 * 4, 0.f);
+  std::vector<float> fq((size_t)4 * 3 * 8 * 64 * 4, 0.f), fo((size_t)4 * 8 * 64 * 4, 0.f);
   const float* W = plan->params.data() + g.w_off; const float* Wo = plan->params.data() + go.w_off;
-  for (int h = 0; h < 4; ++h) for (int wq = 0; wq < 4; ++wq) for (int slot = 0; slot < 2; ++slot) {
-    const int tl = wq + 4 * slot;
-    if (tl >= 6) continue;
+  for (int h = 0; h < 4; ++h) for (int nt = 0; nt < 3; ++nt)
     for (int j = 0; j < 8; ++j) for (int lane = 0; lane < 64; ++lane) {
-      const int d = lane & 31, half = lane >> 5, nrow = (tl % 3) * 128 + h * 32 + d, k = 32 * (j >> 2) + 16 * half + 4 * (j & 3);
-      memcpy(&fq[((((size_t)(h * 4 + wq) * 2 + slot) * 8 + j) * 64 + lane) * 4], W + (size_t)nrow * 64 + k, 16);
+      const int d = lane & 31, half = lane >> 5, nrow = nt * 128 + h * 32 + d, k = 32 * (j >> 2) + 16 * half + 4 * (j & 3);
+      memcpy(&fq[((((size_t)(h * 3 + nt)) * 8 + j) * 64 + lane) * 4], W + (size_t)nrow * 64 + k, 16);
     }
-  }
   for (int nt = 0; nt < 4; ++nt) for (int j = 0; j < 8; ++j) for (int lane = 0; lane < 64; ++lane) {
     const int l = lane & 15, kq = lane >> 4;
     memcpy(&fo[(((size_t)nt * 8 + j) * 64 + lane) * 4], Wo + (size_t)(16 * nt + l) * 128 + 32 * kq + 4 * j, 16);
