@@ -829,14 +829,17 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
     a.pbc_out = m->d_ws + cv.out.off; a.pbc_ld = cv.out.ld; a.pbc_rowpack = cv.rowpack; a.pbc_Cv = cv.rowpack ? cv.Cpad : cv.out.C; a.pbc_H = cv.Hn; a.pbc_W = cv.Wn;
   }
   const int skip = cvt >= 0 ? 4 : 0;
-  auto score_eval = [&]() -> const char* {
+  // The EM predictor rides on the kernel that ends the score net when that is a pixel-kernel run with the score in LDS (pixrun.hip kernel tail):
+  // no guidance (it rewrites the score in between), 8x8 states.  SBM_NO_FUSED_EM=1: the update kernel of its own.
+  const bool fuse_em = !guided && !std::getenv("SBM_NO_FUSED_EM") && P.out_H * P.out_W == 64 && pixrun_can_fuse_em(m->dp);
+  auto score_eval = [&](const StepArgs* em = nullptr) -> const char* {
     const char* e;
     if (time_table) {
       if (guided) launch_fill_time(tbuf, timesteps, m->d_counter, B, st);   // the guidance networks take the step's time per sample (the score net reads the table)
-      e = run_plan(m->dp, x, tbuf, m->d_score, st, 1 | skip);               // the time path comes from the table
+      e = run_plan(m->dp, x, tbuf, m->d_score, st, 1 | skip, em);           // the time path comes from the table
     } else {
       launch_fill_time(tbuf, timesteps, m->d_counter, B, st);
-      e = run_plan(m->dp, x, tbuf, m->d_score, st, skip);
+      e = run_plan(m->dp, x, tbuf, m->d_score, st, skip, em);
     }
     if (e) return e;
     if (guided)                    // classifier / energy guidance on the score just evaluated, at the same x and t (sde_helper2.py:283-312, 65-94)
@@ -856,9 +859,10 @@ static const char* enqueue_step(sbm_model* m, const SdeParams& sp, const sbm_sam
     return nullptr;
   };
   auto predictor = [&](int draw, bool last) -> const char* {
-    const char* e = score_eval(); if (e) return e;
     a.draw = draw; a.noise_draw_off = (long long)draw * B * CHW;
     a.adv_counter = last ? m->d_counter : nullptr; a.adv_ticket = last ? ticket : nullptr;
+    if (fuse_em) return score_eval(&a);
+    const char* e = score_eval(); if (e) return e;
     launch_em_step(a, st);
     return nullptr;
   };

@@ -863,9 +863,10 @@ const char* chain_launch_geometry(int cus, int* grid, int* block) {
   return nullptr;
 }
 
-const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out) {
+const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out, const StepArgs* em) {
   const Plan& plan = *dp.plan;
-  if (dp.use_pix) return launch_pixrun(dp, first, count, st, ext_out);     // pixel mode: the marked ops are sample-owned workgroups (pixrun.hip); no chain tables exist
+  if (dp.use_pix) return launch_pixrun(dp, first, count, st, ext_out, em);
+  if (em) return "chain kernel: the sampler's update cannot ride on this launch";     // pixel mode: the marked ops are sample-owned workgroups (pixrun.hip); no chain tables exist
   if (!dp.chain_ops || !dp.chain_sync) return "chain kernel: no op table";
   for (int i = first; i < first + count; ++i) {
     const Op& op = plan.ops[i];

@@ -177,12 +177,14 @@ struct DevPlan {
   PixState* pix = nullptr;              // ... and their state (owned by the model handle; released by pixrun_release)
 };
 // pixrun.hip: the 4x4 / 2x2 / 1x1 levels, one sample per workgroup, activations in LDS
-const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out = nullptr);   // ext_out: the plan's external NCHW output, for a run that ends in it
+struct StepArgs;
+const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out = nullptr, const StepArgs* em = nullptr);   // ext_out: the plan's external NCHW output, for a run that ends in it; em: the sampler's EM update, applied by the run that ends the plan
+bool pixrun_can_fuse_em(const DevPlan& dp);
 const char* pixrun_prepare(DevPlan& dp, const float* host_params, double* frag_mb);   // host_params: the plan's packed weights (host copy)
 void pixrun_release(DevPlan& dp);
 extern unsigned long long* g_pix_dbg;
 int pixrun_program_ops(const DevPlan& dp, int first, int count, int* kinds, int cap);   // diagnostics: kind * 1000 + taps per program op
-const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out = nullptr);
+const char* launch_chain(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out = nullptr, const StepArgs* em = nullptr);
 const char* chain_launch_geometry(int cus, int* grid, int* block);   // verifies that the whole grid can be resident
 int chain_variant_groups();
 bool qkv_linattn_fusable(const Plan& plan, int i);            // ops i (to_qkv GEMM) and i + 1 (LinearAttention core)
@@ -194,7 +196,7 @@ const char* make_gemm_args(const Plan& plan, const GemmOp& o, const float* prm, 
 
 // Enqueue every op of the plan on `st`.  Returns nullptr or a static error string.  No allocation, no
 // synchronisation: safe to capture into a hipGraph.
-const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops = 0);   // time_ops: 0 all ops, 1 skip the time path, 2 only the time path; + 4: skip the input conversion op
+const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops = 0, const StepArgs* em = nullptr);   // em: see launch_pixrun   // time_ops: 0 all ops, 1 skip the time path, 2 only the time path; + 4: skip the input conversion op
 const char* launch_op(const DevPlan& dp, int op_index, const float* ext_in, float* ext_out, hipStream_t st);
 
 extern unsigned long long* g_gemm_dbg;

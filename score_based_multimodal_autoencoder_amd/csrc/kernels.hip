@@ -2143,12 +2143,13 @@ const char* launch_attn_block(const DevPlan& dp, int i, hipStream_t st) {
   return nullptr;
 }
 
-const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops) {
+const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev, float* ext_out, hipStream_t st, int time_ops, const StepArgs* em) {
   const Plan& plan = *dp.plan;
   if (plan.time_off >= 0 && t_dev && t_dev != dp.ws + plan.time_off)
     if (hipMemcpyAsync(dp.ws + plan.time_off, t_dev, sizeof(float) * plan.B, hipMemcpyDeviceToDevice, st) != hipSuccess) return "time copy failed";
   if (plan.aux_off >= 0 && dp.aux)
     if (hipMemcpyAsync(dp.ws + plan.aux_off, dp.aux, sizeof(float) * plan.B * plan.aux_C, hipMemcpyDeviceToDevice, st) != hipSuccess) return "aux copy failed";
+  bool em_done = false;
   const bool skip_cvt = (time_ops & 4) != 0;        // the caller keeps the converted input current itself (sampler loop)
   time_ops &= 3;
   auto skipped = [&](int i) { return (time_ops == 1 && plan.ops[i].time_path) || (time_ops == 2 && !plan.ops[i].time_path) || (skip_cvt && plan.ops[i].kind == OP_NCHW_TO_PBC); };
@@ -2170,7 +2171,9 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
     }
     if (plan.ops[i].chain) {                        // a maximal run of chain ops is ONE launch
       while (i + n < (int)plan.ops.size() && plan.ops[i + n].chain && !skipped(i + n)) ++n;
-      e = launch_chain(dp, i, n, st, ext_out);
+      const bool ends = i + n == (int)plan.ops.size();
+      if (ends) em_done = em != nullptr;
+      e = launch_chain(dp, i, n, st, ext_out, ends ? em : nullptr);
     } else if (plan.ops[i].row) {                   // ... and so is a run of row-kernel ops (the one-position level)
       while (i + n < (int)plan.ops.size() && plan.ops[i + n].row && !skipped(i + n)) ++n;
       e = launch_rowrun(dp, i, n, st);
@@ -2180,6 +2183,7 @@ const char* run_plan(const DevPlan& dp, const float* ext_in, const float* t_dev,
     if (e) return e;
     i += n;
   }
+  if (em && !em_done) return "run_plan: the sampler's update was to ride on the last launch, which is not a pixel-kernel run";
   if (hipGetLastError() != hipSuccess) return "kernel launch failed";
   return nullptr;
 }

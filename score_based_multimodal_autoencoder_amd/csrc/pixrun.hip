@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "device.h"
+#include "sampler_dev.h"
 
 namespace sbm {
 
@@ -335,7 +336,7 @@ __device__ __forceinline__ void pix_linattn(float* lds, float* scr, int tid, int
 
 __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict__ ops, int count, const PixItem* __restrict__ items, int nitems, const PixStep* __restrict__ steps,
                                                         const unsigned short* __restrict__ rowtab, int nrowtab, const float* __restrict__ frag, const StepCtl* __restrict__ ctl, int B,
-                                                        int act_floats, unsigned long long* dbg, float* __restrict__ ext_out) {
+                                                        int act_floats, unsigned long long* dbg, float* __restrict__ ext_out, const int em_lds, const StepArgs em) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* red = lds + act_floats;                         // [8 waves][512]: 16 rows x 32 columns, or 4 rows x 64 columns
   float* stat = red + P_RED_F;                           // [slots][8 waves][2]: per-wave partial (sum, sumsq); readers add the eight in wave order
@@ -1026,6 +1027,29 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
   }
   // the loads issued for the wrapped-around "next" pass must land before the wave ends
   asm volatile("s_waitcnt vmcnt(0)" ::: PIX_CLOB_0, PIX_CLOB_1, PIX_CLOB_2, PIX_CLOB_3, PIX_CLOB_E);
+  if (em_lds >= 0) {
+    // The sampling loop's EM predictor (sampler.hip em_step_kernel, the same device functions) applied by the kernel that ends the score net: the
+    // last conv left the score of this sample in an LDS slab ([64 pixels][16]); thread q < CHW / 4 takes element quad q = (channel, row, four
+    // columns) of the NCHW state, as a thread of the update kernel would.  The last workgroup to finish moves the step counter on.
+    int tid = tid0; asm volatile("" : "+v"(tid));
+    const int stepi = em.step_counter ? *em.step_counter : em.step_base;
+    if (tid < (em.CHW >> 2)) {
+      const int e = tid * 4, c = e >> 6, r = e & 63;
+      const float t = em.t ? em.t[b] : em.timesteps[stepi];
+      const Coef cf = sde_coef(em.sde, t);
+      const float4 x = *reinterpret_cast<const float4*>(em.x + (long long)b * em.CHW + e);
+      const float* sp = lds + em_lds + (r >> 4) * (2 * PCS) + (c >> 4) * PCS + (r & 15) * 16 + (c & 15);      // pixels r .. r + 3: one 16-row group
+      const float4 s = make_float4(sp[0], sp[16], sp[32], sp[48]);
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!em.sde.probability_flow) z = load_noise4(em, b, e, (unsigned)stepi);
+      float4 m, o;
+      em_update4(em, cf, x, s, z, &m, &o);
+      *reinterpret_cast<float4*>(em.mean_out + (long long)b * em.CHW + e) = m;
+      *reinterpret_cast<float4*>(em.x_out + (long long)b * em.CHW + e) = o;
+      if (em.pbc_out) store_pbc(em, b, e, o);
+    }
+    if (em.adv_counter) advance_by_last_workgroup(em, stepi);
+  }
   if (dbg && b == 0 && tid == 0) dbg[count] = __builtin_amdgcn_s_memtime();
 }
 
@@ -1049,7 +1073,7 @@ struct PFragOp {                          // fragment-order copy of one GEMM op'
 };
 
 struct PProgram { PixOpD* d_ops = nullptr; PixItem* d_items = nullptr; PixStep* d_steps = nullptr; unsigned short* d_rowtab = nullptr;
-                  int n_ops = 0, n_items = 0, n_rowtab = 0, act_floats = 0; bool needs_ext_out = false; std::vector<int> kinds; };
+                  int n_ops = 0, n_items = 0, n_rowtab = 0, act_floats = 0; bool needs_ext_out = false; int em_lds = -1; std::vector<int> kinds; };
 
 }  // namespace
 
@@ -1163,7 +1187,7 @@ struct PBuilder {
   const std::vector<PSlot>* preset = nullptr;
   std::vector<int> touched;
   const char* err = nullptr;
-  bool needs_ext_out = false;
+  bool needs_ext_out = false; int em_lds = -1;
   int run_first = -1, run_stream = -1, run_slots = 0;   // one-position run being assembled: its first program op, the step index of its slot table, its slots
 
   static bool run_kind(int kind) { return kind == PIX_VEC || kind == PIX_DW1 || kind == PIX_GNR1; }
@@ -1417,6 +1441,10 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
         if (fo.small) proto.flags |= PIF_SMALL;
         if (g.out_nchw) {                                   // no slab, no workspace copy: the pass stores into the external tensor (kernel argument)
           proto.flags |= PIF_NCHW; proto.nstore = g.N; proto.out_g = nullptr; proto.out_lds = -1; proto.ldo = 0; b.needs_ext_out = true;
+          if (P_out == 64 && g.N <= 16 && i == (int)plan.ops.size() - 1) {      // ... and, for the sampler's fused EM update (kernel tail), a [64][16] slab of its own
+            View sv; sv.off = (1LL << 40) + i; sv.ld = 16; sv.C = 16; sv.H = g.Hout; sv.W = g.Wout;
+            proto.out_lds = b.slab(sv, nullptr); proto.out_sub = PBuilder::sub_floats(16); b.em_lds = proto.out_lds;
+          }
         } else {
         proto.out_g = dp.ws + g.out.off;
         proto.out_lds = b.slab(g.out, nullptr); b.mark_produced(g.out, i);
@@ -1610,7 +1638,7 @@ const char* pixrun_build(const DevPlan& dp, PixState& st, int first, int count, 
   b.ops[0].pad = (int)b.steps.size();                      // the kernel's {kind, passes} table, one entry per program op
   for (const PixOpD& d : b.ops) b.steps.push_back(PixStep{(unsigned)d.kind, (unsigned)(d.kind == OP_GEMM ? d.nitems : 0)});
   PProgram p;
-  p.n_ops = (int)b.ops.size(); p.n_items = (int)b.items.size(); p.n_rowtab = (int)b.rowtab.size() / 16; p.act_floats = act_floats; p.needs_ext_out = b.needs_ext_out;
+  p.n_ops = (int)b.ops.size(); p.n_items = (int)b.items.size(); p.n_rowtab = (int)b.rowtab.size() / 16; p.act_floats = act_floats; p.needs_ext_out = b.needs_ext_out; p.em_lds = b.em_lds;
   for (const PixOpD& d : b.ops) p.kinds.push_back(d.kind * 1000 + (d.kind == OP_GEMM ? d.nitems : 0));
   auto up = [&](void** dst, const void* src, size_t bytes) -> bool {
     if (hipMalloc(dst, bytes ? bytes : 16) != hipSuccess) return false;
@@ -1702,18 +1730,30 @@ static const PProgram* pix_program(const DevPlan& dp, int first, int count, cons
   return &it->second;
 }
 
-const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out) {
+// true when the program that ends the plan can apply the sampler's EM update itself (launch_pixrun's `em`)
+bool pixrun_can_fuse_em(const DevPlan& dp) {
+  if (!dp.pix || !dp.use_pix) return false;
+  const int nops = (int)dp.plan->ops.size();
+  std::lock_guard<std::mutex> lock(dp.pix->mu);
+  for (const auto& kv : dp.pix->programs) if ((int)(kv.first / 4096) + (int)(kv.first % 4096) == nops && kv.second.em_lds >= 0) return true;
+  return false;
+}
+
+const char* launch_pixrun(const DevPlan& dp, int first, int count, hipStream_t st, float* ext_out, const StepArgs* em) {
   if (!dp.pix) return "pixel kernel: the model has no pixel state";
   const Plan& plan = *dp.plan;
   const char* err = nullptr;
   const PProgram* p = pix_program(dp, first, count, &err);
   if (!p) return err;
   if (p->needs_ext_out && !ext_out) return "pixel kernel: the run ends in the plan's external output, which this call does not have";
+  if (em && (p->em_lds < 0 || em->B != plan.B || em->CHW > 4 * PNT || (em->CHW & 63))) return "pixel kernel: this run cannot apply the sampler's update";
+  const int em_lds = em ? p->em_lds : -1;
+  const StepArgs em_args = em ? *em : StepArgs{};
   const dim3 grid(plan.B), block(PNT);
   const size_t ldsb = pix_lds_bytes(p->act_floats, p->n_rowtab);
   if (g_prof_start) hipExtLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, g_prof_start, g_prof_stop, 0, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab,
-                                          dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg, ext_out);
-  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab, dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg, ext_out);
+                                          dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg, ext_out, em_lds, em_args);
+  else hipLaunchKernelGGL(pixrun_kernel, grid, block, ldsb, st, p->d_ops, p->n_ops, p->d_items, p->n_items, p->d_steps, p->d_rowtab, p->n_rowtab, dp.pix->d_frag, dp.ctl, plan.B, p->act_floats, g_pix_dbg, ext_out, em_lds, em_args);
   return nullptr;
 }
 

@@ -384,6 +384,42 @@ def test_update_kernels_that_advance_and_convert_leave_the_trajectory_bit_identi
     m.release_engines()
 
 
+def test_em_update_applied_by_the_score_nets_last_kernel_is_bit_identical(pkg):
+    """Round 4: in a sampling loop the EM predictor is applied by the pixel-kernel run that ends the score net (the score never leaves LDS; same
+    device functions as em_step_kernel, pixrun.hip kernel tail).  Against the loop with the update kernel of its own (SBM_NO_FUSED_EM): not a bit
+    may differ -- predictor only, predictor-corrector in both orders, graph and eager, the conditional loop, x_mean included."""
+    import os
+    m = _unet(pkg, "P5")
+    sde = pkg["sde"].VPSDE(0.1, 5.0, 40)
+    for B in (7, 256):
+        x0 = torch.randn(B, 5, 8, 8, device="cuda")
+        for kw in (dict(), dict(pc=True, order="cp"), dict(pc=True, order="pc"), dict(use_graph=False), dict(probability_flow=True)):
+            outs = []
+            for env in ({}, {"SBM_NO_FUSED_EM": "1"}):
+                os.environ.update(env)
+                try:
+                    m.release_engines()
+                    assert m._engine_for(B, 8, 8).info["uses_pix"]
+                    outs.append(pkg["sde"].uncond_sampler(tuple(x0.shape), m, "cuda", sde, x0=x0, seed=11, **kw).clone())
+                finally:
+                    for k in env:
+                        os.environ.pop(k, None)
+            assert torch.isfinite(outs[0]).all()
+            assert torch.equal(outs[0], outs[1]), (B, kw)
+    z_obs = torch.randn(7, 5, 64, device="cuda"); xc = torch.randn(7, 5, 8, 8, device="cuda")
+    outs = []
+    for env in ({}, {"SBM_NO_FUSED_EM": "1"}):
+        os.environ.update(env)
+        try:
+            m.release_engines()
+            outs.append(pkg["sde"].cond_sampler(z_obs.view(7, 5, 8, 8), [0, 2], m, sde, seed=3, noise_obs=True, x0=xc).clone())
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    assert torch.equal(outs[0], outs[1])
+    m.release_engines()
+
+
 def test_one_position_runs_match_the_mfma_path(pkg):
     """Round 4: the 1x1 level of the pixel kernel runs as vector-ALU mat-vecs streamed through the AGPR ring (PIX_VEC runs) instead of
     4-row MFMA passes (SBM_PIX_VEC=0): same results to float32 reassociation, forward and a 30-step sampler run, at B = 3 and at the bench's
@@ -408,6 +444,37 @@ def test_one_position_runs_match_the_mfma_path(pkg):
             a, b = res["vec"][i], res["mfma"][i]
             assert float((a - b).abs().max()) <= (2e-5 if i == 0 else 1e-4) * float(b.abs().max()), (B, i)
     m.release_engines()
+
+
+def test_first_last_conv_and_attention_block_inside_the_sample_owned_kernels(pkg):
+    """Round 4: init_conv (im2col op + 1x1 conv) and the conv that writes the NCHW output run inside the pixel kernel's runs (SBM_PIX_IO=0: their
+    own seg_gemm launches), the 8x8 attention block is ONE attnblock_kernel launch (SBM_ATTN_BLOCK=0: to_qkv + core as one kernel, to_out.0 and
+    GroupNorm + residual in the pixel kernel).  Same results to float32 reassociation: forward and a 30-step sampler run, at B = 3 and B = 256,
+    for the 5-modality net and for a 2-modality one (K = 98 of the im2col's 256 columns live)."""
+    import os
+    sde = pkg["sde"].VPSDE(0.1, 5.0, 30)
+    for name, C in (("P5", 5), ("P2", 2)):
+        m = _unet(pkg, name)
+        for B in (3, 256):
+            x = torch.randn(B, C, 8, 8, device="cuda"); t = torch.rand(B, device="cuda")
+            res = {}
+            for tag, env in (("new", {}), ("noio", {"SBM_PIX_IO": "0"}), ("noblock", {"SBM_ATTN_BLOCK": "0"}), ("neither", {"SBM_PIX_IO": "0", "SBM_ATTN_BLOCK": "0"})):
+                os.environ.update(env)
+                try:
+                    m.release_engines()
+                    y = m(x, t).clone()
+                    info = m._engine_for(B, 8, 8).info
+                    assert info["uses_pix"]
+                    res[tag] = (y, pkg["sde"].uncond_sampler((B, C, 8, 8), m, "cuda", sde, x0=x, seed=5).clone())
+                finally:
+                    for k in env:
+                        os.environ.pop(k, None)
+            for tag in ("noio", "noblock", "neither"):
+                for i in (0, 1):
+                    a, b = res["new"][i], res[tag][i]
+                    assert torch.isfinite(a).all()
+                    assert float((a - b).abs().max()) <= (2e-5 if i == 0 else 1e-4) * float(b.abs().max()), (name, B, tag, i)
+        m.release_engines()
 
 
 def test_chain_kernel_matches_per_layer_kernels_at_bench_size(pkg):
