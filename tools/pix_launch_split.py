@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The two pixrun_kernel launches of a config-2 sampler step, reported SEPARATELY: rocprofv3's --stats row averages a 7-op launch
-(the two 8x8 ConvNeXt blocks in front of the 8x8 attention) with a 70-odd-op launch (everything behind it).
+(init_conv and the two 8x8 ConvNeXt blocks in front of the 8x8 attention block) with a 70-odd-op launch (everything behind it).
 
     rocprofv3 --kernel-trace -d DIR -o t --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
     python3 tools/pix_launch_split.py DIR
@@ -19,7 +19,7 @@ if not d:
 cut = (min(d) + max(d)) / 2
 short = [x for x in d if x < cut]; long_ = [x for x in d if x >= cut]
 print(f"pixrun_kernel dispatches: {len(d)}  (average of all {statistics.mean(d):.1f} us)")
-for name, v in (("launch 1 (two 8x8 ConvNeXt blocks, 7 program ops)", short), ("launch 2 (every level behind the 8x8 attention)", long_)):
+for name, v in (("launch 1 (init_conv as im2col + 1x1 conv, the two 8x8 ConvNeXt blocks)", short), ("launch 2 (every level behind the 8x8 attention block, the last conv, the EM update)", long_)):
     if v:
         print(f"  {name}: {len(v)} dispatches, mean {statistics.mean(v):.1f} us, median {statistics.median(v):.1f}, min {min(v):.1f}, max {max(v):.1f}")
 print(f"  per SDE step (one of each): {statistics.mean(short) + statistics.mean(long_):.1f} us" if short and long_ else "")
