@@ -230,12 +230,16 @@ __device__ __forceinline__ int sbyte(const int* w, int r) { return (int)(signed 
                "global_load_dwordx4 a[" #A8 ":" #A11 "], %0, %3\n\t" \
                "global_load_dwordx4 a[" #A12 ":" #A15 "], %0, %4" \
                :: "v"(v0), "s"(b0), "s"(b1), "s"(b2), "s"(b3) : CLOB)
+#ifdef PIX_EXP_NOLOAD_VEC      // timing-only build (tools/build_variant.sh): the one-position runs without their weight stream
+#define PIX_VLOAD_SLOT(r, base_) do { asm volatile("" :: "s"(base_), "v"(vo0)); } while (0)
+#else
 #define PIX_VLOAD_SLOT(r, base_) do { \
     const float* b1_ = (base_) + 2048; const float* b2_ = (base_) + 4096; const float* b3_ = (base_) + 6144; \
     if ((r) == 0) PIX_VRING_LOAD(vo0, base_, b1_, b2_, b3_, 40, 43, 44, 47, 48, 51, 52, 55, PIX_CLOB_0); \
     else if ((r) == 1) PIX_VRING_LOAD(vo0, base_, b1_, b2_, b3_, 56, 59, 60, 63, 64, 67, 68, 71, PIX_CLOB_1); \
     else if ((r) == 2) PIX_VRING_LOAD(vo0, base_, b1_, b2_, b3_, 72, 75, 76, 79, 80, 83, 84, 87, PIX_CLOB_2); \
     else PIX_VRING_LOAD(vo0, base_, b1_, b2_, b3_, 88, 91, 92, 95, 96, 99, 100, 103, PIX_CLOB_3); } while (0)
+#endif
 // One step: four ring registers out of the AGPRs and straight into the accumulator, in ONE asm statement -- given the values as C++ objects hipcc
 // fetched a whole slot first and, short of VGPRs, parked the surplus in a104 / a105: the pending pass's epilogue operands (the build audit
 // caught it).  The first step of a slot waits for the slot's loads.
