@@ -46,6 +46,12 @@ namespace {
 
 typedef float f32x4p __attribute__((ext_vector_type(4)));
 
+// conditions that are false in production launches (stamps, debug sub-ranges): their blocks go to the end of the function, out of the hot lines
+#ifdef PIX_EXP_GOTO1
+#define PIX_COLD(c) (c)
+#else
+#define PIX_COLD(c) __builtin_expect(!!(c), 0)
+#endif
 constexpr int PNT = 512, PNW = 8;         // threads / waves per workgroup (2 waves per SIMD)
 constexpr int PD = 4;                     // ring depth in steps (4 KB per wave and step)
 constexpr int PCS = 272;                  // floats per LDS chunk: 17 rows x 16 k
@@ -433,7 +439,19 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     const PixStep kk = ldc_step(opk + k);
 #endif
     const int kind = (int)kk.w_off;
-    if (dbg && b == 0 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();
+    if (PIX_COLD(dbg) && b == 0 && tid == 0) dbg[k] = __builtin_amdgcn_s_memtime();
+    // A GEMM op -- half of the program's ops -- goes straight to its code.  Through the chain of `if (kind == ...)` below it walked seven compare blocks
+    // that sit KILOBYTES apart (each behind the body of the kind before it): seven instruction-cache lines nobody keeps warm, 0.43 us from the top of
+    // every GEMM op to its first pass (-DPIX_STAMP_PRE, round 4).
+#ifndef PIX_EXP_NOGOTO
+    if (kind == OP_GEMM) goto gemm_op;
+#ifndef PIX_EXP_GOTO1
+    if (kind == OP_DWCONV7) goto dw_op;                   // (the other kinds likewise: all compares here, in one or two lines, one far jump each)
+    if (kind == OP_LINATTN) goto attn_op;
+    if (kind == OP_GN_RES) goto gnres_op;
+    if (kind != PIX_STAGE && kind != OP_IM2COL) goto vec_run;
+#endif
+#endif
     if (kind == PIX_STAGE) {
       // (an opaque copy of the thread index: what is derived from it here stays here.  hipcc hoists every cheap tid expression of every branch
       //  in front of the op loop and keeps it for the whole kernel -- forty of them in a0 .. a39, and the ones that did not fit in scratch)
@@ -488,6 +506,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       __syncthreads();
       continue;
     }
+  dw_op:
     if (kind == OP_DWCONV7) {
       int tid = tid0; asm volatile("" : "+v"(tid));
       const int lane = tid & 63;
@@ -587,7 +606,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       s = wave_sum(s); qq = wave_sum(qq);
       const int so = ldc(&op.stat_out);
       if (lane == 0 && so >= 0) { stat[(so * PNW + wave) * 2] = s; stat[(so * PNW + wave) * 2 + 1] = qq; }
-      if (ldc(&op.stat_g)) {                              // the plan's layout is one partial per pixel: the whole sum goes to pixel 0 (debug sub-ranges only)
+      if (PIX_COLD(ldc(&op.stat_g))) {                              // the plan's layout is one partial per pixel: the whole sum goes to pixel 0 (debug sub-ranges only)
         if (lane == 0) { red[wave] = s; red[PNW + wave] = qq; }      // (not scr: at 8x8 it holds the staged weights other waves may still be reading)
         __syncthreads();
         if (tid == 0) {
@@ -601,6 +620,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       __syncthreads();
       continue;
     }
+  gnres_op:
     if (kind == OP_GN_RES) {
       int tid = tid0; asm volatile("" : "+v"(tid));
       float su, sq;
@@ -626,6 +646,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       __syncthreads();
       continue;
     }
+  attn_op:
     if (kind == OP_LINATTN) {
       int tid = tid0; asm volatile("" : "+v"(tid));
       // LinearAttention core (unet_model.py:169-175) of one sample: n <= 16 positions, heads x 32 channels; q | k | v in one slab
@@ -636,6 +657,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       else pix_linattn<4>(lds, scr, tid, in_lds, out_lds, heads, scale, aout, aldo, B, b);
       continue;
     }
+  vec_run:
     if (kind == PIX_VEC || kind == PIX_DW1 || kind == PIX_GNR1) {
       // A RUN of one-position ops (the 1x1 level and the strided convolution that enters it), v_run program ops long.  On the MFMA path such an
       // op costs 4.4 us around a 1.3 us K loop -- partial tiles through LDS, two barriers, a 512-thread epilogue for 128 .. 256 outputs.  Two
@@ -691,9 +713,9 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
         if (touch == 0x7f5a5a5a) asm volatile("s_nop 0");     // (consumes the previous op's touch: never true)
         touch = ldc(recs + 16 * (j + 1 < run ? j + 1 : j));      // first touch of the NEXT op's record line, a whole op ahead
         const int kd = rc[0] & 0xff;
-        if (dbg && b == 0 && tid == 0 && j > 0) dbg[k + j] = __builtin_amdgcn_s_memtime();
+        if (PIX_COLD(dbg) && b == 0 && tid == 0 && j > 0) dbg[k + j] = __builtin_amdgcn_s_memtime();
 #ifdef PIX_STAMP_VEC
-#define VSTAMP(ph) do { if (dbg && b == 0 && tid == 0 && k + j < 96) dbg[128 + (k + j) * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define VSTAMP(ph) do { if (PIX_COLD(dbg) && b == 0 && tid == 0 && k + j < 96) dbg[128 + (k + j) * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define VSTAMP(ph) do { } while (0)
 #endif
@@ -784,14 +806,14 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             lds[out_lds + pix_at(col, 0)] = ot;
             ov = ot;
           }
-          if (slow && own) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.out_g)[(long long)b * ldc(&o.v_ldo) + col] = ot; }
+          if (PIX_COLD(slow) && own) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.out_g)[(long long)b * ldc(&o.v_ldo) + col] = ot; }
         } else if (kd == (PIX_DW1 & 0xff)) {
           // depth-wise 7x7 at one position = its centre tap (unet_model.py:115 at 1x1; SURVEY appendix A "degenerate sizes")
           if (tid < rc[8]) {
             const float a = fmaf(lds[rc[6] + pix_at(tid, 0)], qe0, 0.f);
             ov = a + (qe1 + qe2);
             lds[out_lds + pix_at(tid, 0)] = ov;
-            if (slow) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.dw.out)[(long long)b * ldc(&o.dw.ldo) + tid] = ov; }
+            if (PIX_COLD(slow)) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.dw.out)[(long long)b * ldc(&o.dw.ldo) + tid] = ov; }
           }
         } else {
           // GroupNorm(1, C)(u) + x at one position (LinearAttention tail + Residual, unet_model.py:173-175, 21-27)
@@ -805,7 +827,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             const float u = lds[rc[6] + pix_at(tid, 0)], x = lds[rc[7] + pix_at(tid, 0)];
             const float y = ((u - mean) * rstd) * qe0 + qe1 + x;
             lds[out_lds + pix_at(tid, 0)] = y;
-            if (slow) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.gr.out)[(long long)b * ldc(&o.gr.ldo) + tid] = y; }
+            if (PIX_COLD(slow)) { const PixOpD& o = ops[k + j]; if (ldc(&o.out_g)) ldc(&o.gr.out)[(long long)b * ldc(&o.gr.ldo) + tid] = y; }
           }
         }
         if (j + 1 < run) { const i32x16p rn = ldc_x16(recs + 16 * (j + 1)); PIX_REQUEST_SMALL(rn); }
@@ -815,7 +837,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
           if (lane == 0) { stat[(so * PNW + wave) * 2] = sacc; stat[(so * PNW + wave) * 2 + 1] = qacc; }
         }
         __syncthreads();
-        if (slow) {                                         // the plan's partial layouts (debug sub-ranges only): one (sum, sumsq) per 32-column block of a
+        if (PIX_COLD(slow)) {                                         // the plan's partial layouts (debug sub-ranges only): one (sum, sumsq) per 32-column block of a
           const PixOpD& o = ops[k + j];                     // GEMM's output, one per pixel for the depth-wise op
           if (ldc(&o.stat_g) && tid == 0) {
             float su, sq;
@@ -838,7 +860,8 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
       continue;
     }
     // ---------------------------------------------------------------- GEMM: everything comes from the item table
-#define PSTAMP_AT(ph) do { if (dbg && b == 0 && tid == 0 && ci < 96) dbg[128 + ci * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
+  gemm_op:
+#define PSTAMP_AT(ph) do { if (PIX_COLD(dbg) && b == 0 && tid == 0 && ci < 96) dbg[128 + ci * 4 + (ph)] = __builtin_amdgcn_s_memtime(); } while (0)
     // default: four phase stamps per pass (K loop | partial tiles + barrier | epilogue + barrier).  -DPIX_STAMP_EPI / -DPIX_STAMP_PRE (diagnostic
     // builds, tools/build_variant.sh) move the four stamps INSIDE the epilogue / the pass prologue instead: PSTAMP_X(id)
 #if defined(PIX_STAMP_EPI)
@@ -1009,7 +1032,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
             }
             sacc += o[0] + o[1] + o[2] + o[3]; qacc += o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
           }
-          if (stat_g) {                                    // the plan's partial layout: one (sum, sumsq) per (pixel, 32-column block) = 8 consecutive threads
+          if (PIX_COLD(stat_g)) {                                    // the plan's partial layout: one (sum, sumsq) per (pixel, 32-column block) = 8 consecutive threads
             float s32 = o[0] + o[1] + o[2] + o[3], q32 = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
 #pragma unroll
             for (int m = 1; m < 8; m <<= 1) { s32 += __shfl_xor(s32, m); q32 += __shfl_xor(q32, m); }
@@ -1054,7 +1077,7 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
     }
     if (em.adv_counter) advance_by_last_workgroup(em, stepi);
   }
-  if (dbg && b == 0 && tid == 0) dbg[count] = __builtin_amdgcn_s_memtime();
+  if (PIX_COLD(dbg) && b == 0 && tid == 0) dbg[count] = __builtin_amdgcn_s_memtime();
 }
 
 // ------------------------------------------------------------------------------------------------
