@@ -244,6 +244,15 @@ void interpret(const Plan& plan, std::vector<float>& ws, const float* in, const 
           ws[o.off + ((int64_t)p * c.B + b) * o.ld + ch] = v;
         }
       } break;
+      case OP_IM2COL: {                                  // pixel mode: init_conv's input matrix from the row-packed image (plan.h Im2colOp)
+        const Im2colOp& o = op.ic; const int taps = o.KH * o.KW;
+        for (int p = 0; p < o.H * o.W; ++p) for (int b = 0; b < o.B; ++b) for (int k = 0; k < o.out.ld; ++k) {
+          const int c = k / taps, r = k % taps, iy = p / o.W + r / o.KW - o.pad, ix = p % o.W + r % o.KW - o.pad;
+          float v = 0.f;
+          if (c < o.C && iy >= 0 && iy < o.H && ix >= 0 && ix < o.W) v = ws[o.in.off + ((int64_t)iy * o.B + b) * o.in.ld + ix * o.Cpad + c];
+          ws[o.out.off + ((int64_t)p * o.B + b) * o.out.ld + k] = v;
+        }
+      } break;
       case OP_BILINEAR: run_bilinear(op.bl, ws.data()); break;
       case OP_AVGPOOL: {
         const BilinearOp& o = op.bl; const int k = o.scale, Ho = o.out.H, Wo = o.out.W, Wi = o.in.W;

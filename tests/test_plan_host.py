@@ -45,6 +45,29 @@ def test_unet_plan_matches_reference(golden, name):
     np.testing.assert_array_equal(plan.run(x, t, want.shape), y)
 
 
+@pytest.mark.parametrize("name", ["P2", "P5"])
+def test_unet_pixel_mode_plan_matches_reference(golden, name, monkeypatch):
+    """The plan as the product builds it for the sample-owned kernels (pixel mode: init_conv as an im2col op + a 1x1 conv over 256 columns, the
+    last conv and the attention block marked for their kernels, pinned buffers) computes the REFERENCE's output too -- on the host interpreter,
+    op by op from the same descriptors -- and differs from the default plan exactly where it should."""
+    g = golden("unet_forward.npz")
+    c = UNET_CASES[name]
+    x, t, want = g[f"{name}_x"], g[f"{name}_t"], g[f"{name}_y"]
+    sd = synth.fill_state_dict(arch.unet_state_shapes(**c))
+    cfg = planref.unet_cfg_ints(c["dim"], c["channels"], c["dim_mults"], x.shape[2], x.shape[3])
+    monkeypatch.setenv("SBMREF_PIX", "1")
+    plan = planref.RefPlan(0, cfg, x.shape[0], sd)
+    monkeypatch.delenv("SBMREF_PIX")
+    y = plan.run(x, t, want.shape)
+    assert_close(y, want, 1e-5, 1e-5 * np.abs(want).max(), name)
+    np.testing.assert_array_equal(plan.run(x, t, want.shape), y)
+    names = [plan.op_name(i).split(":", 1)[-1] for i in range(400) if plan.op_name(i)]
+    assert "init_conv im2col" in names and "init_conv (1x1 over im2col)" in names and "init_conv (row-packed)" not in names
+    ref = planref.RefPlan(0, cfg, x.shape[0], sd)
+    ref_names = [ref.op_name(i).split(":", 1)[-1] for i in range(400) if ref.op_name(i)]
+    assert "init_conv (row-packed)" in ref_names and "init_conv im2col" not in ref_names
+
+
 def test_unet_plan_flop_accounting():
     c = UNET_CASES["P5"]
     sd = synth.fill_state_dict(arch.unet_state_shapes(**c))
