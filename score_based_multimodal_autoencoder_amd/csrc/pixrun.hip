@@ -1,9 +1,11 @@
-// pixrun.hip -- the low-resolution levels of the score net (4x4, 2x2, 1x1) as ONE launch of SAMPLE-OWNED workgroups.
+// pixrun.hip -- every level of an 8x8 score net (8x8, 4x4, 2x2, 1x1) as RUNS of ops executed by SAMPLE-OWNED workgroups: for the PolyMNIST nets two
+// launches per forward (the 8x8 attention block between them is kernels.hip attnblock_kernel), which in a sampling loop also hold init_conv (an im2col
+// op + a 1x1 conv), the conv that writes the NCHW score, and the EM update (kernel tail) -- DESIGN.md 3b', 3b'', 3b'''.
 //
-// Nothing in the network mixes samples, so a workgroup takes ONE sample through the whole run of low-resolution ops alone: no barrier
+// Nothing in the network mixes samples, so a workgroup takes ONE sample through a whole run of ops alone: no barrier
 // ever leaves the workgroup, the sample's activations stay in LDS from the first op to the last, and the run's weights are streamed
-// from L2 (all workgroups of an XCD walk the same bytes in the same order).  Round 3 rewrite; what the measurements behind it say
-// (tools/pixgemm_probe.hip, profiles/r03_pixgemm_probe.txt):
+// from L2 (all workgroups of an XCD walk the same bytes in the same order).  Round 3 rewrite, round 4 additions; what the measurements behind it
+// say (tools/pixgemm_probe.hip, profiles/r03_pixgemm_probe.txt):
 //
 //   weights   : streamed in MFMA FRAGMENT order, packed on the host at model creation, so that every wave-load is 1 KB contiguous:
 //               118 GB/s per workgroup (30 TB/s out of the L2s) against 37 GB/s for 64-byte row segments of a [n][k] matrix.
@@ -370,11 +372,13 @@ __global__ __launch_bounds__(PNT, 1) void pixrun_kernel(const PixOpD* __restrict
   const float* cond_tab = nullptr;
   if (ctl && ctl->table_mode) cond_tab = ctl->table + (long long)ctl->step * ctl->tab_ld;
   __syncthreads();
+  // the eight waves' partial (sum, sumsq) of a slot are 64 contiguous bytes: four 16-byte reads and a fixed three-level tree (sixteen 4-byte reads and
+  // two chains of eight dependent adds before: every reader of statistics -- each mat-vec, each folded GroupNorm -- waits for this)
   auto stat_sum = [&](int slot, float* su, float* sq) {
-    float a = 0.f, q = 0.f;
-#pragma unroll
-    for (int w = 0; w < PNW; ++w) { a += stat[(slot * PNW + w) * 2]; q += stat[(slot * PNW + w) * 2 + 1]; }
-    *su = a; *sq = q;
+    const float4* sp = reinterpret_cast<const float4*>(stat + slot * PNW * 2);
+    const float4 v0 = sp[0], v1 = sp[1], v2 = sp[2], v3 = sp[3];
+    *su = ((v0.x + v0.z) + (v1.x + v1.z)) + ((v2.x + v2.z) + (v3.x + v3.z));
+    *sq = ((v0.y + v0.w) + (v1.y + v1.w)) + ((v2.y + v2.w) + (v3.y + v3.w));
   };
   // ---- loader state (per wave; survives the non-GEMM ops between two GEMMs) ----
   unsigned asel[PD];
